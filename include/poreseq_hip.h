@@ -1,0 +1,143 @@
+/*
+ * poreseq_hip.h — C ABI of libporeseq_hip.so, the MI355X (gfx950) implementation of
+ * PoreSeq's event-level HMM scoring path.
+ *
+ * Every entry point replaces one function the reference's Cython binding
+ * (poreseq/_poreseqcpp.pyx) calls in the reference C++ core; the reference
+ * interface each one stands in for is cited as file:line relative to the
+ * reference tree.  Only plain pointers and sizes cross this boundary.
+ *
+ * All functions return PS_OK (0) or a negative ps_status; ps_last_error()
+ * gives the message of the last failure on the calling thread.  The library
+ * never falls back to a CPU implementation: without a usable HIP device every
+ * compute call fails with PS_ERR_NO_DEVICE.
+ *
+ * Indices follow the reference: mutation `start` is a 0-based base index,
+ * ref_align values are 1-based state indices (0 = unaligned, -1 = inserted
+ * level), Smith-Waterman index lists are 1-based with 0 = gap.
+ */
+#ifndef PORESEQ_HIP_H_
+#define PORESEQ_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_N_STATES 1024 /* cpp/AlignUtil.h:19 */
+
+typedef enum ps_status {
+    PS_OK = 0,
+    PS_ERR_BAD_ARG = -1,     /* NULL pointer, negative size, negative mutation start ... */
+    PS_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init */
+    PS_ERR_HIP = -3,         /* a HIP call failed */
+    PS_ERR_UNSUPPORTED = -4, /* e.g. realign_width > 511 (band wider than one workgroup) */
+    PS_ERR_NOMEM = -5
+} ps_status;
+
+const char* ps_last_error(void);
+/* Name of the backend that serves this ABI ("hip-gfx950"); the test-only
+ * oracle and reference shims answer "oracle-cpu" / "reference-cpp". */
+const char* ps_backend_name(void);
+
+/* AlignParams — cpp/AlignUtil.h:57-66 (defaults 4.5 / 150 / 300 / 0). */
+typedef struct ps_params {
+    double lik_offset;
+    int32_t scoring_width;
+    int32_t realign_width;
+    int32_t verbose;
+} ps_params;
+
+/* ---- AlignData (cpp/AlignData.h:26-35): sequence + events + params (+ seed-likelihood cache) ---- */
+typedef struct ps_align ps_align;
+
+/* Replaces PythonToAlignData / PythonToEvents (_poreseqcpp.pyx:99-153), i.e.
+ * Sequence(seq) (cpp/Sequence.h:31-34), EventData::setData (cpp/EventData.h:208-224),
+ * ModelData::setData / setParams (cpp/EventData.h:48-73).
+ *   level_off[E+1]      CSR offsets of each event's levels in mean/stdv/ref_align/ref_like
+ *   model[E][4][1024]   level_mean, level_stdv, sd_mean, sd_stdv
+ *   trans[E][4]         prob_skip, prob_stay, prob_extend, prob_insert
+ *   evseq/evseq_off     each event's own 2D base-called sequence (may be NULL)
+ * Everything is copied; the caller keeps ownership of its buffers. */
+int ps_align_create(ps_align** out, const char* seq, int64_t seq_len, int32_t n_events,
+                    const int64_t* level_off, const double* mean, const double* stdv,
+                    const double* ref_align, const double* ref_like, const double* model,
+                    const double* trans, const char* evseq, const int64_t* evseq_off,
+                    const ps_params* params);
+void ps_align_destroy(ps_align* a);
+/* `data.params.scoring_width = params['point_width']` (_poreseqcpp.pyx:293-294, 361-362, 465-466). */
+int ps_align_set_scoring_width(ps_align* a, int32_t width);
+int32_t ps_align_n_events(const ps_align* a);
+int64_t ps_align_n_levels(const ps_align* a, int32_t ev);
+int64_t ps_align_sequence_length(const ps_align* a);
+/* data.sequence.bases (_poreseqcpp.pyx:375, 433, 470); `out` needs sequence_length bytes (no NUL). */
+int ps_align_get_sequence(const ps_align* a, char* out, int64_t cap);
+/* UpdatePythonEvents (_poreseqcpp.pyx:131-137): copy one event's ref_align / ref_like out. */
+int ps_align_get_event_refs(const ps_align* a, int32_t ev, double* ref_align, double* ref_like);
+
+/* ---- vector<MutInfo> / vector<MutScore> (cpp/AlignUtil.h:69-91) ---- */
+typedef struct ps_muts ps_muts;
+/* orig_off / mut_off are CSR offsets [n+1] into the two byte pools; score may be
+ * NULL (then every score is the MutScore seed -1e-6, cpp/AlignUtil.h:86). */
+int ps_muts_create(ps_muts** out, int64_t n, const int32_t* start, const int64_t* orig_off,
+                   const char* orig_pool, const int64_t* mut_off, const char* mut_pool,
+                   const double* score);
+void ps_muts_destroy(ps_muts* m);
+int64_t ps_muts_count(const ps_muts* m);
+int64_t ps_muts_orig_bytes(const ps_muts* m);
+int64_t ps_muts_mut_bytes(const ps_muts* m);
+int ps_muts_export(const ps_muts* m, int32_t* start, int64_t* orig_off, char* orig_pool,
+                   int64_t* mut_off, char* mut_pool, double* score);
+
+/* ---- vector<Sequence> results (ViterbiMutate) ---- */
+typedef struct ps_seqs ps_seqs;
+void ps_seqs_destroy(ps_seqs* s);
+int64_t ps_seqs_count(const ps_seqs* s);
+int64_t ps_seqs_bytes(const ps_seqs* s);
+int ps_seqs_export(const ps_seqs* s, int64_t* off /*[count+1]*/, char* pool);
+
+/* ---- the five free functions of cpp/Mutations.h:18-24 ---- */
+
+/* ScoreAlignments (cpp/MakeMutations.cpp:148-195): forward fill + backtrace per event;
+ * scores[E]; likes (NULL or [sequence_length], accumulated into, as the reference does). */
+int ps_score_alignments(ps_align* a, double* scores, double* likes);
+/* FindPointMutations (cpp/FindMutations.cpp:191-234). */
+int ps_find_point_mutations(ps_align* a, ps_muts** out);
+/* FindMutations (cpp/FindMutations.cpp:24-186); seed sequences as a CSR string pool. */
+int ps_find_mutations(ps_align* a, int32_t n_seqs, const int64_t* seq_off, const char* seq_pool,
+                      ps_muts** out);
+/* ScoreMutations (cpp/MakeMutations.cpp:23-69): same order as the input list.  Re-aligns
+ * every event as a side effect, as the reference does. */
+int ps_score_mutations(ps_align* a, const ps_muts* muts, ps_muts** out_scored);
+/* MakeMutations (cpp/MakeMutations.cpp:74-146): greedy application, returns mutated-base count. */
+int ps_make_mutations(ps_align* a, const ps_muts* scored, int32_t* n_bases);
+
+/* ViterbiMutate (cpp/Viterbi.h:67-68, cpp/Viterbi.cpp:239-426).  Uses libc rand() for the
+ * nkeep > 0 stochastic back-traces exactly as the reference does (never seeded). */
+int ps_viterbi_mutate(ps_align* a, int32_t nkeep, double skip_prob, double stay_prob,
+                      double mut_min, double mut_max, int32_t verbose, ps_seqs** out);
+
+/* swfull (cpp/swlib.h:36, cpp/swlib.cpp:211-340).  inds1/inds2 need room for n1+n2 entries. */
+int ps_swfull(const char* seq1, int64_t n1, const char* seq2, int64_t n2, int32_t* score,
+              double* accuracy, int32_t* inds1, int32_t* inds2, int64_t cap, int64_t* n_pairs);
+/* Sequence::populateStates (cpp/Sequence.h:64-100); states needs max(n-4,0) entries. */
+int ps_seq_to_states(const char* seq, int64_t n, int32_t* states, int64_t* n_states);
+
+/* ---- kernel-level test hooks (K1/K2 matrices vs oracle dumps) ----
+ * Runs Alignment::update (cpp/Alignment.cpp:63-73) for one event on the current sequence
+ * and returns the dense (n_levels+1) x (n_states+1) forward or backward main matrix with
+ * out-of-band cells as NaN; direction 0 = forward (column index = ref position), 1 = backward
+ * (column index k = -col, cpp/Alignment.cpp:284-285).  stay (may be NULL) gets the stay matrix. */
+int ps_debug_fill(ps_align* a, int32_t ev, int32_t direction, double* main, double* stay,
+                  uint8_t* step_main, uint8_t* step_stay);
+
+/* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
+ * algorithmic bytes of the named kernel class ("fill", "score", "viterbi", "sw") since reset. */
+int ps_prof_reset(void);
+int ps_prof_get(const char* name, double* ms, int64_t* launches, double* alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PORESEQ_HIP_H_ */
