@@ -1,0 +1,205 @@
+// ps_api.cpp — the C ABI of include/poreseq_hip.h over the HIP implementation.
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "ps_host.h"
+
+using namespace ps;
+
+struct ps_align { Align a; };
+struct ps_muts { std::vector<Mut> v; };
+struct ps_seqs { std::vector<std::string> v; };
+
+#define NEED_RT()            \
+    Runtime* rt = nullptr;   \
+    PS_TRY(runtime(&rt))
+
+extern "C" {
+
+const char* ps_last_error(void) { return last_error(); }
+const char* ps_backend_name(void) { return "hip-gfx950"; }
+
+int ps_align_create(ps_align** out, const char* seq, int64_t seq_len, int32_t n_events,
+                    const int64_t* level_off, const double* mean, const double* stdv,
+                    const double* ref_align, const double* ref_like, const double* model,
+                    const double* trans, const char* evseq, const int64_t* evseq_off,
+                    const ps_params* params) {
+    if (!out || !seq || seq_len < 0 || n_events < 0 ||
+        (n_events && (!level_off || !mean || !stdv || !ref_align || !ref_like || !model || !trans)))
+        return fail(PS_ERR_BAD_ARG, "ps_align_create: bad argument");
+    NEED_RT();
+    std::unique_ptr<ps_align> h(new ps_align());
+    PS_TRY(h->a.create(rt, seq, seq_len, n_events, level_off, mean, stdv, ref_align, ref_like, model, trans,
+                       evseq, evseq_off, params));
+    *out = h.release();
+    return PS_OK;
+}
+void ps_align_destroy(ps_align* a) { delete a; }
+int ps_align_set_scoring_width(ps_align* a, int32_t w) {
+    if (!a) return fail(PS_ERR_BAD_ARG, "null handle");
+    a->a.par.scoring_width = w;
+    return PS_OK;
+}
+int32_t ps_align_n_events(const ps_align* a) { return a ? a->a.E : 0; }
+int64_t ps_align_n_levels(const ps_align* a, int32_t e) { return (a && e >= 0 && e < a->a.E) ? a->a.n[e] : -1; }
+int64_t ps_align_sequence_length(const ps_align* a) { return a ? (int64_t)a->a.bases.size() : -1; }
+int ps_align_get_sequence(const ps_align* a, char* out, int64_t cap) {
+    if (!a || !out || cap < (int64_t)a->a.bases.size()) return fail(PS_ERR_BAD_ARG, "ps_align_get_sequence");
+    memcpy(out, a->a.bases.data(), a->a.bases.size());
+    return PS_OK;
+}
+int ps_align_get_event_refs(const ps_align* ca, int32_t e, double* ra, double* rl) {
+    ps_align* a = const_cast<ps_align*>(ca);
+    if (!a || e < 0 || e >= a->a.E) return fail(PS_ERR_BAD_ARG, "ps_align_get_event_refs");
+    NEED_RT();
+    PS_TRY(a->a.refs_to_host(rt));
+    const int64_t o = a->a.off[e];
+    if (ra) memcpy(ra, a->a.h_ra.data() + o, a->a.n[e] * sizeof(double));
+    if (rl) memcpy(rl, a->a.h_rl.data() + o, a->a.n[e] * sizeof(double));
+    return PS_OK;
+}
+
+int ps_muts_create(ps_muts** out, int64_t n, const int32_t* start, const int64_t* oo, const char* op,
+                   const int64_t* mo, const char* mp, const double* score) {
+    if (!out || n < 0 || (n && (!start || !oo || !mo))) return fail(PS_ERR_BAD_ARG, "ps_muts_create");
+    ps_muts* m = new ps_muts();
+    m->v.resize(n);
+    for (int64_t i = 0; i < n; i++) {
+        m->v[i].start = start[i];
+        if (oo[i + 1] > oo[i]) m->v[i].orig.assign(op + oo[i], op + oo[i + 1]);
+        if (mo[i + 1] > mo[i]) m->v[i].mut.assign(mp + mo[i], mp + mo[i + 1]);
+        m->v[i].score = score ? score[i] : -1e-6;
+    }
+    *out = m;
+    return PS_OK;
+}
+void ps_muts_destroy(ps_muts* m) { delete m; }
+int64_t ps_muts_count(const ps_muts* m) { return m ? (int64_t)m->v.size() : 0; }
+int64_t ps_muts_orig_bytes(const ps_muts* m) { int64_t t = 0; if (m) for (auto& x : m->v) t += x.orig.size(); return t; }
+int64_t ps_muts_mut_bytes(const ps_muts* m) { int64_t t = 0; if (m) for (auto& x : m->v) t += x.mut.size(); return t; }
+int ps_muts_export(const ps_muts* m, int32_t* start, int64_t* oo, char* op, int64_t* mo, char* mp, double* score) {
+    if (!m) return fail(PS_ERR_BAD_ARG, "ps_muts_export");
+    int64_t a = 0, b = 0;
+    for (size_t i = 0; i < m->v.size(); i++) {
+        const Mut& x = m->v[i];
+        if (start) start[i] = x.start;
+        if (oo) oo[i] = a;
+        if (mo) mo[i] = b;
+        if (op) memcpy(op + a, x.orig.data(), x.orig.size());
+        if (mp) memcpy(mp + b, x.mut.data(), x.mut.size());
+        a += x.orig.size(); b += x.mut.size();
+        if (score) score[i] = x.score;
+    }
+    if (oo) oo[m->v.size()] = a;
+    if (mo) mo[m->v.size()] = b;
+    return PS_OK;
+}
+
+void ps_seqs_destroy(ps_seqs* s) { delete s; }
+int64_t ps_seqs_count(const ps_seqs* s) { return s ? (int64_t)s->v.size() : 0; }
+int64_t ps_seqs_bytes(const ps_seqs* s) { int64_t t = 0; if (s) for (auto& x : s->v) t += x.size(); return t; }
+int ps_seqs_export(const ps_seqs* s, int64_t* off, char* pool) {
+    if (!s) return fail(PS_ERR_BAD_ARG, "ps_seqs_export");
+    int64_t a = 0;
+    for (size_t i = 0; i < s->v.size(); i++) {
+        if (off) off[i] = a;
+        if (pool) memcpy(pool + a, s->v[i].data(), s->v[i].size());
+        a += s->v[i].size();
+    }
+    if (off) off[s->v.size()] = a;
+    return PS_OK;
+}
+
+int ps_score_alignments(ps_align* a, double* scores, double* likes) {
+    if (!a || (!scores && a->a.E)) return fail(PS_ERR_BAD_ARG, "ps_score_alignments");
+    NEED_RT();
+    return score_alignments(rt, &a->a, scores, likes);
+}
+int ps_find_point_mutations(ps_align* a, ps_muts** out) {
+    if (!a || !out) return fail(PS_ERR_BAD_ARG, "ps_find_point_mutations");
+    ps_muts* m = new ps_muts();
+    find_point_mutations(&a->a, &m->v);
+    *out = m;
+    return PS_OK;
+}
+int ps_find_mutations(ps_align* a, int32_t n, const int64_t* off, const char* pool, ps_muts** out) {
+    if (!a || !out || n < 0 || (n && (!off || !pool))) return fail(PS_ERR_BAD_ARG, "ps_find_mutations");
+    NEED_RT();
+    std::vector<std::string> seeds;
+    for (int i = 0; i < n; i++) seeds.emplace_back(pool + off[i], pool + off[i + 1]);
+    std::unique_ptr<ps_muts> m(new ps_muts());
+    PS_TRY(find_mutations(rt, &a->a, seeds, &m->v));
+    *out = m.release();
+    return PS_OK;
+}
+int ps_score_mutations(ps_align* a, const ps_muts* in, ps_muts** out) {
+    if (!a || !in || !out) return fail(PS_ERR_BAD_ARG, "ps_score_mutations");
+    NEED_RT();
+    std::unique_ptr<ps_muts> m(new ps_muts());
+    PS_TRY(score_mutations(rt, &a->a, in->v, &m->v));
+    *out = m.release();
+    return PS_OK;
+}
+int ps_make_mutations(ps_align* a, const ps_muts* in, int32_t* nb) {
+    if (!a || !in || !nb) return fail(PS_ERR_BAD_ARG, "ps_make_mutations");
+    NEED_RT();
+    int n = 0;
+    PS_TRY(make_mutations(rt, &a->a, in->v, &n));
+    *nb = n;
+    return PS_OK;
+}
+int ps_viterbi_mutate(ps_align* a, int32_t nkeep, double skip, double stay, double mmin, double mmax,
+                      int32_t, ps_seqs** out) {
+    if (!a || !out || a->a.E == 0 || nkeep < 0) return fail(PS_ERR_BAD_ARG, "ps_viterbi_mutate");
+    NEED_RT();
+    std::unique_ptr<ps_seqs> s(new ps_seqs());
+    PS_TRY(viterbi_mutate(rt, &a->a, nkeep, skip, stay, mmin, mmax, &s->v));
+    *out = s.release();
+    return PS_OK;
+}
+int ps_swfull(const char* s1, int64_t n1, const char* s2, int64_t n2, int32_t* score, double* acc,
+              int32_t* i1, int32_t* i2, int64_t cap, int64_t* np) {
+    if (!s1 || !s2 || n1 < 0 || n2 < 0 || !np) return fail(PS_ERR_BAD_ARG, "ps_swfull");
+    NEED_RT();
+    int sc = 0; double ac = 0;
+    std::vector<int> a, b;
+    PS_TRY(sw_device(rt, std::string(s1, n1), std::string(s2, n2), &sc, &ac, &a, &b));
+    if ((int64_t)a.size() > cap) return fail(PS_ERR_BAD_ARG, "ps_swfull: index capacity too small");
+    if (score) *score = sc;
+    if (acc) *acc = ac;
+    for (size_t k = 0; k < a.size(); k++) { if (i1) i1[k] = a[k]; if (i2) i2[k] = b[k]; }
+    *np = (int64_t)a.size();
+    return PS_OK;
+}
+int ps_seq_to_states(const char* seq, int64_t n, int32_t* st, int64_t* ns) {
+    if (!seq || n < 0 || !ns) return fail(PS_ERR_BAD_ARG, "ps_seq_to_states");
+    std::vector<int> v = states_of(std::string(seq, n));  // pure index arithmetic, no DP: host
+    if (st) std::copy(v.begin(), v.end(), st);
+    *ns = (int64_t)v.size();
+    return PS_OK;
+}
+
+int ps_debug_fill(ps_align* a, int32_t e, int32_t dir, double* main, double* stay, uint8_t* sm, uint8_t* ss) {
+    if (!a || e < 0 || e >= a->a.E || !main || dir < 0 || dir > 1) return fail(PS_ERR_BAD_ARG, "ps_debug_fill");
+    NEED_RT();
+    return debug_fill(rt, &a->a, e, dir, main, stay, sm, ss);
+}
+
+int ps_prof_reset(void) {
+    NEED_RT();
+    rt->prof.clear();
+    rt->prof_on = true;
+    return PS_OK;
+}
+int ps_prof_get(const char* name, double* ms, int64_t* n, double* bytes) {
+    NEED_RT();
+    Prof p;
+    if (name) { auto it = rt->prof.find(name); if (it != rt->prof.end()) p = it->second; }
+    if (ms) *ms = p.ms;
+    if (n) *n = p.launches;
+    if (bytes) *bytes = p.bytes;
+    return PS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// ps_debug.cpp — ps_debug_fill: dump one event's dense DP matrices (test hook).
+#include <cmath>
+
+#include "ps_host.h"
+
+namespace ps {
+
+// Alignment::update (cpp/Alignment.cpp:63-73) for one event, then un-skew the device matrices.
+int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* stay, uint8_t* sm, uint8_t* ss) {
+    std::vector<JobSpec> specs(1);
+    specs[0].ev = ev; specs[0].states = &a->states;
+    specs[0].ra = a->d_ra + a->off[ev]; specs[0].rl = a->d_rl + a->off[ev]; specs[0].ri = a->d_ri + a->off[ev];
+    Batch b;
+    PS_TRY(b.build(rt, a, specs, 2, 0));
+    b.d.out = a->d_out + ev;
+    PS_TRY(realign(rt, a, b, 0));
+    a->host_refs_valid = false;
+    const JobD& J = b.jobs[0];
+    const int n0 = J.n0, C = J.C, P = J.P;
+    const size_t ld = (size_t)C + 1, tot = ((size_t)n0 + 1) * ld;
+    const double nan = std::nan("");
+    for (size_t k = 0; k < tot; k++) { main[k] = nan; if (stay) stay[k] = nan; if (sm) sm[k] = 0; if (ss) ss[k] = 0; }
+    JobOut o;
+    PS_HIP(hipMemcpyAsync(&o, a->d_out + ev, sizeof(o), hipMemcpyDeviceToHost, rt->stream));
+    std::vector<int> lb(J.lbn);
+    PS_HIP(hipMemcpyAsync(lb.data(), b.d.lb + J.lb_off, J.lbn * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
+    std::vector<double2> rec((size_t)J.S * P);
+    std::vector<unsigned short> flg((size_t)J.S * P);
+    PS_HIP(hipMemcpyAsync(rec.data(), b.d.rec + J.mat_off[dir], rec.size() * sizeof(double2), hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipMemcpyAsync(flg.data(), b.d.flg + J.mat_off[dir], flg.size() * sizeof(unsigned short), hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    // column 0 is the blank column: rows 0..n0, all zero (cpp/Alignment.cpp:42-43)
+    for (int i = 0; i <= n0; i++) { main[(size_t)i * ld] = 0.0; if (stay) stay[(size_t)i * ld] = 0.0; }
+    if (o.inert) return PS_OK;
+    for (int c = 1; c <= C; c++) {
+        int ce;
+        if (dir == 0) { int v = lb[c]; ce = v < 0 ? 1 : v; }
+        else { int v = lb[C - c + 1]; ce = v < 0 ? 1 : n0 - v + 1; }
+        ce = std::min(std::max(ce, 1), n0);
+        const int i0 = std::max(1, ce - J.W), i1 = std::min(n0, ce + J.W);
+        for (int i = i0; i <= i1; i++) {
+            const size_t at = (size_t)(i + c) * P + (i % P);
+            const size_t to = (size_t)i * ld + c;
+            main[to] = rec[at].x;
+            if (stay) stay[to] = rec[at].y;
+            if (sm) sm[to] = (uint8_t)(flg[at] & 255);
+            if (ss) ss[to] = (uint8_t)(flg[at] >> 8);
+        }
+    }
+    return PS_OK;
+}
+
+}  // namespace ps

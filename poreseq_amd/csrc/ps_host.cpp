@@ -1,0 +1,500 @@
+// ps_host.cpp — host side of libporeseq_hip.so: runtime, AlignData, batching, and the
+// refinement-loop logic that the reference keeps in C++ above its Alignment class
+// (cpp/MakeMutations.cpp, cpp/FindMutations.cpp, cpp/EventUtil.cpp, cpp/Sequence.h).
+// All dynamic-programming arithmetic runs in the HIP kernels (ps_kernels.hip, ps_sw.hip,
+// ps_viterbi.hip); there is no CPU implementation of it in this library.
+#include "ps_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+namespace ps {
+
+static thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+const char* last_error() { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------ runtime
+int DBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return PS_OK;
+    if (p) { PS_HIP(hipFree(p)); p = nullptr; cap = 0; }
+    size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+    if (hipMalloc(&p, want) != hipSuccess) {
+        p = nullptr;
+        want = std::max<size_t>(bytes, 1 << 16);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(PS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    }
+    cap = want;
+    return PS_OK;
+}
+
+int runtime(Runtime** out) {
+    static Runtime R;
+    static int state = 0;  // 0 untried, 1 ok, -1 failed
+    static std::string why;
+    if (state == 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            state = -1;
+            why = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                  "); libporeseq_hip has no CPU fallback";
+        } else {
+            int dev = 0;
+            if (const char* s = getenv("PORESEQ_DEVICE")) dev = atoi(s);
+            else if (const char* s2 = getenv("LOCAL_RANK")) dev = atoi(s2) % n;
+            if (dev < 0 || dev >= n) dev = 0;
+            hipDeviceProp_t prop;
+            if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+                hipStreamCreate(&R.stream) != hipSuccess || hipEventCreate(&R.ev0) != hipSuccess ||
+                hipEventCreate(&R.ev1) != hipSuccess) {
+                state = -1; why = "HIP device initialisation failed";
+            } else if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+                state = -1; why = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+            } else {
+                R.device = dev; R.ready = true; state = 1;
+            }
+        }
+    }
+    if (state < 0) return fail(PS_ERR_NO_DEVICE, why);
+    *out = &R;
+    return PS_OK;
+}
+
+void prof_begin(Runtime* rt) { if (rt->prof_on) hipEventRecord(rt->ev0, rt->stream); }
+void prof_end(Runtime* rt, const char* name, double bytes) {
+    if (!rt->prof_on) return;
+    hipEventRecord(rt->ev1, rt->stream);
+    hipEventSynchronize(rt->ev1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, rt->ev0, rt->ev1);
+    Prof& p = rt->prof[name];
+    p.ms += ms; p.launches += 1; p.bytes += bytes;
+}
+
+// ------------------------------------------------------------------------------------------ sequences
+// Sequence::populateStates, cpp/Sequence.h:64-100
+std::vector<int> states_of(const std::string& bases) {
+    std::vector<int> st;
+    if (bases.size() < 5) return st;
+    auto code = [](char c) -> int { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : (int)(signed char)c; };
+    int cur = 0;
+    for (int i = 0; i < 4; i++) cur = (cur << 2) + code(bases[i]);
+    st.resize(bases.size() - 4);
+    for (size_t i = 4; i < bases.size(); i++) {
+        if (code(bases[i - 4]) < 4) { cur = (NS - 1) & ((cur << 2) + code(bases[i])); st[i - 4] = cur; }
+        else { cur = 0; st[i - 4] = -1; }
+    }
+    return st;
+}
+
+// Sequence(original, mut), cpp/Sequence.h:37-59
+std::string apply_edit(const std::string& b, const Mut& m) {
+    if ((size_t)m.start >= b.size()) return b;
+    std::string r = b.substr(0, m.start);
+    r += m.mut;
+    size_t rem = (size_t)m.start + m.orig.size();
+    if (rem < b.size()) r += b.substr(rem);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ batch
+int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int ndir_, int lb_extra, bool matrices) {
+    ndir = ndir_;
+    const int W = a->par.realign_width;
+    if (W < 0) return fail(PS_ERR_BAD_ARG, "realign_width < 0");
+    P = std::max(64, ((2 * W + 1 + 63) / 64) * 64);
+    if (P > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 511: band wider than one workgroup");
+    jobs.clear();
+    maxS = 0; maxC = 0; maxn = 0; maxlbn = 0;
+    int64_t st_tot = 0, lb_tot = 0, lo_tot = 0, mat_tot = 0, col_tot = 0;
+    std::vector<int> h_states;
+    std::map<const std::vector<int>*, int64_t> st_seen;
+    for (const JobSpec& s : specs) {
+        JobD j;
+        memset(&j, 0, sizeof(j));
+        j.ev = s.ev; j.n0 = a->n[s.ev]; j.C = (int)s.states->size(); j.W = W; j.P = P;
+        j.force_inert = (W == 0) ? 1 : 0;
+        j.lbn = j.C + 2 + lb_extra;
+        j.lev_off = a->off[s.ev];
+        auto it = st_seen.find(s.states);
+        if (it == st_seen.end()) {
+            st_seen[s.states] = st_tot; j.st_off = st_tot;
+            h_states.insert(h_states.end(), s.states->begin(), s.states->end());
+            st_tot += j.C;
+        } else j.st_off = it->second;
+        j.lb_off = lb_tot; lb_tot += j.lbn;
+        j.lbn_off = lb_tot; lb_tot += j.lbn;
+        j.S = (int64_t)j.n0 + j.C + 1;
+        for (int d = 0; d < ndir; d++) {
+            j.mat_off[d] = mat_tot; if (matrices) mat_tot += j.S * P;
+            j.lo_off[d] = lo_tot; lo_tot += j.S;
+            j.col_off[d] = col_tot; col_tot += j.C + 1;
+        }
+        j.ra = s.ra; j.rl = s.rl; j.ri = s.ri;
+        maxS = std::max(maxS, j.S); maxC = std::max(maxC, j.C); maxn = std::max(maxn, j.n0); maxlbn = std::max(maxlbn, j.lbn);
+        jobs.push_back(j);
+    }
+    PS_TRY(rt->buf("jobs").ensure(jobs.size() * sizeof(JobD)));
+    PS_TRY(rt->buf("states").ensure(std::max<size_t>(h_states.size(), 1) * sizeof(int)));
+    PS_TRY(rt->buf("lb").ensure(std::max<int64_t>(lb_tot, 1) * sizeof(int)));
+    PS_TRY(rt->buf("lo").ensure(std::max<int64_t>(lo_tot, 1) * sizeof(int)));
+    PS_TRY(rt->buf("rec").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double2)));
+    PS_TRY(rt->buf("flg").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short)));
+    PS_TRY(rt->buf("cmax").ensure(std::max<int64_t>(col_tot, 1) * sizeof(double)));
+    PS_TRY(rt->buf("cmaxrow").ensure(std::max<int64_t>(col_tot, 1) * sizeof(int)));
+    PS_TRY(rt->buf("pm").ensure(std::max<int64_t>(col_tot, 1) * sizeof(double)));
+    PS_HIP(hipMemcpyAsync(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD), hipMemcpyHostToDevice, rt->stream));
+    if (!h_states.empty())
+        PS_HIP(hipMemcpyAsync(rt->buf("states").p, h_states.data(), h_states.size() * sizeof(int), hipMemcpyHostToDevice, rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));  // the staging vectors die with this scope
+    cells = mat_tot;
+    d.jobs = rt->buf("jobs").as<JobD>();
+    d.njobs = (int)jobs.size();
+    d.mean = a->d_mean; d.stdv = a->d_stdv; d.logstdv = a->d_lsd; d.model = a->d_model; d.trans = a->d_trans;
+    d.states = rt->buf("states").as<int>();
+    d.lb = rt->buf("lb").as<int>(); d.lo = rt->buf("lo").as<int>();
+    d.rec = rt->buf("rec").as<double2>(); d.flg = rt->buf("flg").as<unsigned short>();
+    d.cmax = rt->buf("cmax").as<double>(); d.cmaxrow = rt->buf("cmaxrow").as<int>(); d.pm = rt->buf("pm").as<double>();
+    d.lik_offset = a->par.lik_offset;
+    d.log2pi = std::log(2 * M_PI);  // cpp/AlignUtil.h:24
+    return PS_OK;
+}
+
+// bytes the fills of this batch move by the SURVEY 8(d) accounting: 18 B (fwd) / 16 B (back) per band cell
+double Batch::fill_alg_bytes(const Align* a) const {
+    double t = 0;
+    for (const JobD& j : jobs) {
+        const double band = std::min<double>(2.0 * j.W + 1, j.n0);
+        t += (double)j.C * band * (ndir == 2 ? 34.0 : 18.0) + 24.0 * j.n0 * ndir;
+    }
+    (void)a;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------ AlignData
+Align::~Align() {
+    if (slab) hipFree(slab);
+}
+
+int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_events, const int64_t* level_off,
+                  const double* mean, const double* stdv, const double* ref_align, const double* ref_like,
+                  const double* model, const double* trans, const char* evseq, const int64_t* evseq_off,
+                  const ps_params* params) {
+    bases.assign(seq, (size_t)seq_len);
+    states = states_of(bases);
+    if (params) par = *params;
+    E = n_events;
+    n.resize(E); off.resize(E + 1);
+    for (int e = 0; e <= E; e++) off[e] = E ? level_off[e] - level_off[0] : 0;
+    for (int e = 0; e < E; e++) { n[e] = (int)(off[e + 1] - off[e]); if (n[e] < 0) return fail(PS_ERR_BAD_ARG, "level_off not monotone"); }
+    ntot = E ? off[E] : 0;
+    const int64_t base = E ? level_off[0] : 0;
+    evseqs.resize(E);
+    if (evseq && evseq_off) for (int e = 0; e < E; e++) evseqs[e].assign(evseq + evseq_off[e], evseq + evseq_off[e + 1]);
+    h_mean.assign(mean + base, mean + base + ntot);
+    h_stdv.assign(stdv + base, stdv + base + ntot);
+    h_ra.assign(ref_align + base, ref_align + base + ntot);
+    h_rl.assign(ref_like + base, ref_like + base + ntot);
+    host_refs_valid = true;
+    // derived model columns with the host libm, exactly as ModelData::setData / setParams (cpp/EventData.h:48-73)
+    std::vector<double> lsd(ntot), mdl((size_t)E * 6 * NS), tr((size_t)E * 4);
+    for (int64_t t = 0; t < ntot; t++) lsd[t] = std::log(h_stdv[t]);
+    for (int e = 0; e < E; e++) {
+        const double* src = model + (size_t)e * 4 * NS;
+        double* dst = mdl.data() + (size_t)e * 6 * NS;
+        for (int k = 0; k < NS; k++) {
+            const double lm = src[k], ls = src[NS + k], sm = src[2 * NS + k], ss = src[3 * NS + k];
+            const double lam = std::pow(sm, 3) / std::pow(ss, 2);
+            dst[k] = lm; dst[NS + k] = ls; dst[2 * NS + k] = std::log(ls);
+            dst[3 * NS + k] = sm; dst[4 * NS + k] = lam; dst[5 * NS + k] = std::log(lam);
+        }
+        for (int k = 0; k < 4; k++) tr[e * 4 + k] = std::log(trans[e * 4 + k]);
+    }
+    h_model = mdl;
+    // one slab: mean, stdv, lsd, ra, rl, ri [ntot each] | model | trans | out
+    const size_t nlev = (size_t)std::max<int64_t>(ntot, 1);
+    const size_t bytes = 6 * nlev * sizeof(double) + (mdl.size() + tr.size() + 2) * sizeof(double) +
+                         (size_t)std::max(E, 1) * sizeof(JobOut) + 64 * 16;
+    PS_HIP(hipMalloc(&slab, bytes));
+    char* p = (char*)slab;
+    auto carve = [&](size_t b) { char* r = p; p += (b + 63) / 64 * 64; return r; };
+    d_mean = (double*)carve(nlev * 8); d_stdv = (double*)carve(nlev * 8); d_lsd = (double*)carve(nlev * 8);
+    d_ra = (double*)carve(nlev * 8); d_rl = (double*)carve(nlev * 8); d_ri = (double*)carve(nlev * 8);
+    d_model = (double*)carve(std::max<size_t>(mdl.size(), 1) * 8); d_trans = (double*)carve(std::max<size_t>(tr.size(), 1) * 8);
+    d_out = (JobOut*)carve((size_t)std::max(E, 1) * sizeof(JobOut));
+    if (ntot) {
+        PS_HIP(hipMemcpyAsync(d_mean, h_mean.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
+        PS_HIP(hipMemcpyAsync(d_stdv, h_stdv.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
+        PS_HIP(hipMemcpyAsync(d_lsd, lsd.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
+        PS_HIP(hipMemcpyAsync(d_ra, h_ra.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
+        PS_HIP(hipMemcpyAsync(d_rl, h_rl.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
+    }
+    if (E) {
+        PS_HIP(hipMemcpyAsync(d_model, mdl.data(), mdl.size() * 8, hipMemcpyHostToDevice, rt->stream));
+        PS_HIP(hipMemcpyAsync(d_trans, tr.data(), tr.size() * 8, hipMemcpyHostToDevice, rt->stream));
+    }
+    PS_HIP(hipMemsetAsync(d_out, 0, (size_t)std::max(E, 1) * sizeof(JobOut), rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    // EventData::setData ends with updaterefs() (cpp/EventData.h:223)
+    Batch b;
+    PS_TRY(base_batch(rt, &b, 1, 0, false));
+    PS_TRY(launch_updaterefs(rt, b.d));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    return PS_OK;
+}
+
+int Align::base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra, bool matrices) {
+    std::vector<JobSpec> specs(E);
+    for (int e = 0; e < E; e++) {
+        specs[e].ev = e; specs[e].states = &states;
+        specs[e].ra = d_ra + off[e]; specs[e].rl = d_rl + off[e]; specs[e].ri = d_ri + off[e];
+    }
+    PS_TRY(b->build(rt, this, specs, ndir, lb_extra, matrices));
+    b->d.out = d_out;
+    return PS_OK;
+}
+
+int Align::refs_to_host(Runtime* rt) {
+    if (host_refs_valid || !ntot) { host_refs_valid = true; return PS_OK; }
+    PS_HIP(hipMemcpyAsync(h_ra.data(), d_ra, ntot * 8, hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipMemcpyAsync(h_rl.data(), d_rl, ntot * 8, hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    host_refs_valid = true;
+    return PS_OK;
+}
+
+// forward fill + backtrace + updaterefs of a batch (the body of ScoreAlignments per event,
+// cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
+int realign(Runtime* rt, Align* a, Batch& b, int lb_extra_ready) {
+    (void)lb_extra_ready;
+    PS_TRY(launch_begin(rt, b.d));
+    PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
+    if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes(a);
+    PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P));
+    PS_TRY(launch_colstats(rt, b.d, b.ndir, b.maxC));
+    PS_TRY(launch_backtrace(rt, b.d, b.maxn));
+    PS_TRY(launch_updaterefs(rt, b.d));
+    return PS_OK;
+}
+
+// ScoreAlignments, cpp/MakeMutations.cpp:148-195
+int score_alignments(Runtime* rt, Align* a, double* scores, double* likes) {
+    if (!a->E) return PS_OK;
+    Batch b;
+    PS_TRY(a->base_batch(rt, &b, 1, 0));
+    PS_TRY(realign(rt, a, b, 0));
+    a->host_refs_valid = false;
+    std::vector<JobOut> out(a->E);
+    PS_HIP(hipMemcpyAsync(out.data(), a->d_out, a->E * sizeof(JobOut), hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    for (int e = 0; e < a->E; e++) scores[e] = std::max(out[e].best, 0.0);  // Alignment::getMax, cpp/Alignment.h:127-130
+    if (likes) {
+        PS_TRY(a->refs_to_host(rt));
+        for (int e = 0; e < a->E; e++) accumulate_likes(a->h_ra.data() + a->off[e], a->h_rl.data() + a->off[e], a->n[e], (int)a->states.size(), likes);
+    }
+    return PS_OK;
+}
+
+// the `likes` loop of ScoreAlignments, cpp/MakeMutations.cpp:168-189 (one event)
+void accumulate_likes(const double* ra, const double* rl, int n, int C, double* likes) {
+    double last = 0;
+    int refind = 1;
+    for (int t = 0; t < n; t++) {
+        if (ra[t] > 0) {
+            for (int k = refind; k < ra[t]; k++) likes[k + 1] += last;
+            last = rl[t];
+            refind = (int)ra[t];
+        }
+    }
+    for (int64_t k = refind; k < (int64_t)C + 3; k++) likes[k + 1] += last;
+}
+
+// states of the edited sequence at columns sidx+1 .. sidx+ncol, without building the whole sequence;
+// equals Sequence(original, mut).states there (cpp/Sequence.h:37-100).  A 12-base look-back flushes
+// every effect of earlier non-ACGT characters (they reach at most 8 states ahead).
+static void edited_window(const std::string& b, const Mut& m, int sidx, int ncol, int* out) {
+    const bool copy = (size_t)m.start >= b.size();
+    const int64_t L = (int64_t)b.size();
+    const int64_t cut = copy ? L : std::min<int64_t>(L, (int64_t)m.start + (int64_t)m.orig.size());
+    const int64_t mlen = copy ? 0 : (int64_t)m.mut.size();
+    const int64_t Lm = copy ? L : (int64_t)m.start + mlen + (L - cut);
+    auto at = [&](int64_t p) -> char {
+        if (copy || p < m.start) return b[p];
+        if (p < m.start + mlen) return m.mut[p - m.start];
+        return b[cut + (p - m.start - mlen)];
+    };
+    const int64_t lo = std::max<int64_t>(0, (int64_t)sidx - 12);
+    const int64_t hi = std::min<int64_t>(Lm, (int64_t)sidx + ncol + 4);
+    std::string w;
+    w.reserve(hi - lo);
+    for (int64_t p = lo; p < hi; p++) w.push_back(at(p));
+    std::vector<int> st = states_of(w);
+    for (int c = 0; c < ncol; c++) {
+        const int64_t k = (int64_t)sidx + c - lo;
+        out[c] = (k >= 0 && k < (int64_t)st.size()) ? st[k] : -1;
+    }
+}
+
+// ScoreMutations, cpp/MakeMutations.cpp:23-69
+int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::vector<Mut>* out) {
+    *out = muts;
+    for (Mut& m : *out) m.score = -1e-6;
+    const int M = (int)muts.size();
+    for (const Mut& m : muts) if (m.start < 0) return fail(PS_ERR_BAD_ARG, "negative mutation start");
+    if (!a->E) return PS_OK;
+    const int64_t L = (int64_t)a->bases.size();
+    const int C = (int)a->states.size();
+    const int WS = a->par.scoring_width;
+    if (WS < 0) return fail(PS_ERR_BAD_ARG, "scoring_width < 0");
+    // per-edit geometry
+    std::vector<int> h_start(M), h_mlen(M), h_cm(M), h_ncol(M), h_skip(M), h_oldidx(M);
+    int ncolmax = 1, extra = 0;
+    for (int i = 0; i < M; i++) {
+        const Mut& m = muts[i];
+        h_start[i] = m.start; h_mlen[i] = (int)m.mut.size();
+        h_skip[i] = (int64_t)m.start > L ? 1 : 0;  // "sanity check", cpp/MakeMutations.cpp:46-47
+        const bool copy = (int64_t)m.start >= L;
+        const int64_t cut = std::min<int64_t>(L, (int64_t)m.start + (int64_t)m.orig.size());
+        const int64_t Lm = copy ? L : (int64_t)m.start + (int64_t)m.mut.size() + (L - cut);
+        const int Cm = Lm >= 5 ? (int)(Lm - 4) : 0;
+        h_cm[i] = Cm;
+        const int sidx = std::max(m.start - 4, 0);
+        int ncol = std::min<int64_t>((int64_t)m.mut.size() + 6, std::max<int64_t>(0, (int64_t)Cm - sidx));
+        if (WS == 0 || h_skip[i]) ncol = 0;  // stripe_width 0 makes fillColumn a no-op, cpp/Alignment.cpp:118-119
+        h_ncol[i] = ncol;
+        ncolmax = std::max(ncolmax, ncol);
+        if (!h_skip[i]) extra = std::max(extra, sidx + ncol + 1 - (C + 1));
+    }
+    extra = std::max(extra, 0) + 2;
+    if (ncolmax > 64 && WS > 511) return fail(PS_ERR_UNSUPPORTED, "edit longer than 58 bases with scoring_width > 511");
+    std::vector<int> h_states((size_t)M * ncolmax, -1);
+    for (int i = 0; i < M; i++)
+        if (h_ncol[i] > 0) edited_window(a->bases, muts[i], std::max(muts[i].start - 4, 0), h_ncol[i], h_states.data() + (size_t)i * ncolmax);
+    // distinct r0 = max(start - 3, 1)
+    std::vector<int> r0s;
+    {
+        std::map<int, int> idx;
+        for (int i = 0; i < M; i++) {
+            if (h_skip[i]) { h_oldidx[i] = 0; continue; }
+            const int r0 = std::max(muts[i].start - 3, 1);
+            auto it = idx.find(r0);
+            if (it == idx.end()) { it = idx.emplace(r0, (int)r0s.size()).first; r0s.push_back(r0); }
+            h_oldidx[i] = it->second;
+        }
+    }
+    // size classes by new-column count
+    std::vector<int> cls[4];
+    for (int i = 0; i < M; i++) {
+        const int nc = h_ncol[i];
+        cls[nc <= 8 ? 0 : nc <= 16 ? 1 : nc <= 32 ? 2 : 3].push_back(i);
+    }
+    Batch b;
+    PS_TRY(a->base_batch(rt, &b, 2, extra));
+    // upload edit tables
+    const int nr0 = (int)r0s.size();
+    DBuf& mb = rt->buf("mutint");
+    const size_t ints = (size_t)M * 7 + (size_t)M * ncolmax + nr0 + 16;
+    PS_TRY(mb.ensure(ints * sizeof(int)));
+    int* dp = mb.as<int>();
+    std::vector<int> stage;
+    stage.reserve(ints);
+    auto push = [&](const std::vector<int>& v) { int* r = dp + stage.size(); stage.insert(stage.end(), v.begin(), v.end()); return r; };
+    ScoreArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.nitems_per_job = M; sa.ncolmax = ncolmax; sa.ws = WS; sa.nr0 = nr0;
+    sa.m_start = push(h_start); sa.m_mlen = push(h_mlen); sa.m_cm = push(h_cm); sa.m_ncol = push(h_ncol);
+    sa.m_skip = push(h_skip); sa.m_oldidx = push(h_oldidx); sa.m_states = push(h_states); sa.r0 = push(r0s);
+    const int* cls_items[4]; int cls_count[4];
+    for (int k = 0; k < 4; k++) { cls_items[k] = push(cls[k]); cls_count[k] = (int)cls[k].size(); }
+    if (!stage.empty()) PS_HIP(hipMemcpyAsync(dp, stage.data(), stage.size() * sizeof(int), hipMemcpyHostToDevice, rt->stream));
+    DBuf& db = rt->buf("mutdbl");
+    const size_t dbl = (size_t)a->E * std::max(nr0, 1) + (size_t)a->E * std::max(M, 1) + std::max(M, 1);
+    PS_TRY(db.ensure(dbl * sizeof(double)));
+    sa.old = db.as<double>(); sa.delta = sa.old + (size_t)a->E * std::max(nr0, 1); sa.score = sa.delta + (size_t)a->E * std::max(M, 1);
+    // Alignment::update for every event, then every edit against every event
+    PS_TRY(realign(rt, a, b, extra));
+    a->host_refs_valid = false;
+    PS_TRY(launch_lb(rt, b.d, 1, b.maxlbn));
+    if (M) {
+        if (rt->prof_on) {
+            // per (event, edit) item  16(Bs+1) + 16 Br + 24(Bs+c) + 32 Br / k + 8
+            double t = 0;
+            const double Bs = 2.0 * WS + 1, Br = 2.0 * a->par.realign_width + 1;
+            const double k = M ? (double)M / std::max(nr0, 1) : 1;
+            for (int i = 0; i < M; i++) t += 16 * (Bs + 1) + 16 * Br + 24 * (Bs + h_mlen[i] + 6) + 32 * Br / k + 8;
+            rt->prof["score"].bytes += t * a->E;
+        }
+        PS_TRY(launch_score(rt, b.d, sa, cls_items, cls_count));
+        std::vector<double> sc(M);
+        PS_HIP(hipMemcpyAsync(sc.data(), sa.score, M * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
+        PS_HIP(hipStreamSynchronize(rt->stream));
+        for (int i = 0; i < M; i++) (*out)[i].score = sc[i];
+    } else {
+        PS_HIP(hipStreamSynchronize(rt->stream));
+    }
+    return PS_OK;
+}
+
+// FindPointMutations, cpp/FindMutations.cpp:191-234
+void find_point_mutations(const Align* a, std::vector<Mut>* out) {
+    static const char B4[] = "ACGT";
+    out->clear();
+    out->reserve(a->states.size() * 8);
+    for (size_t i = 0; i < a->states.size(); i++) {
+        Mut m;
+        m.start = (int)i;
+        m.orig.assign(1, a->bases[i]);
+        out->push_back(m);
+        for (int k = 0; k < 4; k++) {
+            if (a->bases[i] == B4[k]) continue;
+            m.mut.assign(1, B4[k]);
+            out->push_back(m);
+        }
+        m.orig.clear();
+        for (int k = 0; k < 4; k++) { m.mut.assign(1, B4[k]); out->push_back(m); }
+    }
+}
+
+static bool by_score_desc(const Mut& x, const Mut& y) { return x.score > y.score; }  // cpp/MakeMutations.cpp:16-17
+
+// MakeMutations, cpp/MakeMutations.cpp:74-146.  std::sort with the same comparator on the same
+// libstdc++ gives the reference's (unstable) order for tied scores.
+int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {
+    const int spacing = 10;
+    int nb = 0;
+    std::sort(muts.begin(), muts.end(), by_score_desc);
+    while (!muts.empty() && muts.back().score < 0) muts.pop_back();
+    if (muts.empty()) { *nbases = 0; return PS_OK; }
+    std::vector<Mut> later;
+    bool changed = false;
+    for (size_t i = 0; i < muts.size(); i++) {
+        if (muts[i].score < 0) { later.push_back(muts[i]); continue; }
+        a->bases = apply_edit(a->bases, muts[i]);
+        changed = true;
+        nb += (int)std::max(muts[i].orig.size(), muts[i].mut.size());
+        for (size_t j = i + 1; j < muts.size(); j++) {
+            const int lo = std::max(muts[i].start, muts[j].start);
+            const int hi = (int)std::min(muts[i].start + muts[i].mut.size(), muts[j].start + muts[j].mut.size());
+            if (lo < hi + spacing && muts[j].score > 0) { muts[j].score = -1; continue; }
+            if ((size_t)muts[j].start >= muts[i].start + muts[i].orig.size())
+                muts[j].start += (int)(muts[i].mut.size() - muts[i].orig.size());
+        }
+    }
+    if (changed) a->states = states_of(a->bases);
+    if (later.size() > 10) {
+        std::vector<Mut> rescored;
+        PS_TRY(score_mutations(rt, a, later, &rescored));
+        int more = 0;
+        PS_TRY(make_mutations(rt, a, rescored, &more));
+        nb += more;
+    }
+    *nbases = nb;
+    return PS_OK;
+}
+
+}  // namespace ps

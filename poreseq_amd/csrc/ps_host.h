@@ -1,0 +1,71 @@
+// ps_host.h — host-side structures of libporeseq_hip.so
+#ifndef PS_HOST_H_
+#define PS_HOST_H_
+
+#include "ps_internal.h"
+
+namespace ps {
+
+const char* last_error();
+
+struct Align;
+
+struct JobSpec {
+    int ev = 0;
+    const std::vector<int>* states = nullptr;
+    double *ra = nullptr, *rl = nullptr, *ri = nullptr;  // device arrays of the job
+};
+
+// a set of alignment jobs with all their device workspaces carved out of the runtime pool
+struct Batch {
+    std::vector<JobD> jobs;
+    BatchD d;
+    int ndir = 1, P = 64, maxC = 0, maxn = 0, maxlbn = 0;
+    int64_t maxS = 0, cells = 0;
+    int build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int ndir, int lb_extra, bool matrices = true);
+    double fill_alg_bytes(const Align* a) const;
+};
+
+// AlignData (cpp/AlignData.h:26-35) with the event data resident in HBM
+struct Align {
+    std::string bases;
+    std::vector<int> states;
+    ps_params par = {4.5, 150, 300, 0};  // cpp/AlignUtil.h:64
+    int E = 0;
+    std::vector<int> n;
+    std::vector<int64_t> off;
+    int64_t ntot = 0;
+    std::vector<std::string> evseqs;
+    std::vector<double> h_mean, h_stdv, h_ra, h_rl, h_model;
+    bool host_refs_valid = true;
+    void* slab = nullptr;
+    double *d_mean = nullptr, *d_stdv = nullptr, *d_lsd = nullptr, *d_ra = nullptr, *d_rl = nullptr, *d_ri = nullptr;
+    double *d_model = nullptr, *d_trans = nullptr;
+    JobOut* d_out = nullptr;
+    std::map<std::string, std::vector<double>> seqlikes;  // cpp/AlignData.h:34
+
+    ~Align();
+    int create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_events, const int64_t* level_off,
+               const double* mean, const double* stdv, const double* ref_align, const double* ref_like,
+               const double* model, const double* trans, const char* evseq, const int64_t* evseq_off,
+               const ps_params* params);
+    int base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra, bool matrices = true);
+    int refs_to_host(Runtime* rt);
+};
+
+std::vector<int> states_of(const std::string& bases);
+std::string apply_edit(const std::string& b, const Mut& m);
+void accumulate_likes(const double* ra, const double* rl, int n, int C, double* likes);
+
+int realign(Runtime* rt, Align* a, Batch& b, int);
+int score_alignments(Runtime* rt, Align* a, double* scores, double* likes);
+int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::vector<Mut>* out);
+void find_point_mutations(const Align* a, std::vector<Mut>* out);
+int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases);
+int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds, std::vector<Mut>* out);
+int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, double mmin, double mmax,
+                   std::vector<std::string>* out);
+int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* stay, uint8_t* sm, uint8_t* ss);
+
+}  // namespace ps
+#endif

@@ -1,0 +1,167 @@
+// ps_internal.h — shared declarations of libporeseq_hip.so (host side + kernel launchers).
+//
+// Data layout in HBM:
+//   levels      mean/stdv/logstdv f64, all events concatenated               (read-only per PSAlign call)
+//   models      per event 6 x 1024 f64: lev_mean, lev_stdv, log_lev, sd_mean, sd_lambda, log_lambda
+//   refs        per alignment job ref_align / ref_like / ref_index f64[n0]   (rewritten by the backtrace)
+//   DP matrices per (job, direction): "skewed" storage  REC[s][slot], s = i + j (anti-diagonal),
+//               slot = i mod P, one 16-byte record {main, stay} per cell, plus FLG[s][slot] u16
+//               (band flags before the recurrence pass, {main step, stay step} after it).
+//               One anti-diagonal is one contiguous run of P records: the recurrence kernel's
+//               loads and stores are fully coalesced.
+#ifndef PS_INTERNAL_H_
+#define PS_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/poreseq_hip.h"
+
+namespace ps {
+
+constexpr int NS = PS_N_STATES;
+constexpr double BIG = 1e300;  // "inf" of the reference, cpp/AlignUtil.h:20
+
+// ---- error plumbing ------------------------------------------------------------------------
+int fail(int code, const std::string& msg);
+#define PS_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return ps::fail(PS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+#define PS_TRY(expr)            \
+    do {                        \
+        int _rc = (expr);       \
+        if (_rc != PS_OK) return _rc; \
+    } while (0)
+
+// ---- runtime: device, stream, grow-only device buffers -------------------------------------
+struct DBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);  // grow-only; contents are NOT preserved across growth
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct Prof { double ms = 0; int64_t launches = 0; double bytes = 0; };
+
+struct Runtime {
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, DBuf> pool;
+    std::map<std::string, Prof> prof;
+    bool prof_on = false;
+    DBuf& buf(const std::string& name) { return pool[name]; }
+};
+int runtime(Runtime** out);  // PS_ERR_NO_DEVICE when no usable GPU; never falls back
+
+// ---- mutation list (vector<MutInfo>/vector<MutScore>, cpp/AlignUtil.h:69-91) ----------------
+struct Mut {
+    int start = 0;
+    std::string orig, mut;
+    double score = -1e-6;
+};
+
+// ---- device-side job descriptor: one (event, sequence) alignment ---------------------------
+struct JobD {
+    int ev;          // event index (model / transition rows)
+    int n0;          // levels in the event
+    int C;           // states of the job's sequence
+    int W;           // realign_width (band half-width of the fills)
+    int force_inert; // realign_width == 0: every Alignment is a no-op (cpp/Alignment.cpp:85-86)
+    int P;           // slots per anti-diagonal (multiple of 64, >= 2W+1)
+    int lbn;         // entries in each lb table (C + 2 + extra)
+    int pad0;
+    int64_t lev_off;     // into mean/stdv/logstdv
+    int64_t st_off;      // into the states pool
+    int64_t lb_off;      // lb table the fills were made with          (int32[lbn])
+    int64_t lbn_off;     // lb table after the latest backtrace        (int32[lbn])
+    int64_t mat_off[2];  // record offset of the forward / backward matrix
+    int64_t lo_off[2];   // into LO (int32 per anti-diagonal)
+    int64_t col_off[2];  // into per-column arrays (C+1 entries per direction)
+    int64_t S;           // anti-diagonals: n0 + C + 1
+    double* ra;          // ref_align  [n0]
+    double* rl;          // ref_like   [n0]
+    double* ri;          // ref_index  [n0]
+};
+
+// per job results living in device memory
+struct JobOut {
+    double best;      // forward maxScore.score after the last column
+    int bi, bj;       // its cell
+    int has_index;    // ref_index non-empty after the latest updaterefs
+    int refstart, refend;
+    int inert;        // latched at the start of an API call: the reference's stripe_width == 0
+};
+
+// device pointers of everything a batch of jobs needs (filled by Batch::upload)
+struct BatchD {
+    const JobD* jobs;
+    JobOut* out;
+    int njobs;
+    const double *mean, *stdv, *logstdv;  // concatenated levels
+    const double* model;                  // [E][6][1024]
+    const double* trans;                  // [E][4] log probabilities: skip, stay, extend, insert
+    const int* states;                    // pool
+    int* lb;                              // pool of lb tables
+    int* lo;                              // pool
+    double2* rec;                         // matrices
+    unsigned short* flg;
+    double* cmax;                         // per column max of main
+    int* cmaxrow;                         // first row achieving it
+    double* pm;                           // prefix max over columns (MaxInfo.score per column)
+    double lik_offset;
+    double log2pi;
+};
+
+// ---- kernel launchers (ps_kernels.hip) ------------------------------------------------------
+int launch_updaterefs(Runtime* rt, const BatchD& b);
+int launch_lb(Runtime* rt, const BatchD& b, int which /*0: lb_off, 1: lbn_off*/, int maxlbn);
+int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P);
+int launch_colstats(Runtime* rt, const BatchD& b, int ndir, int maxC);
+int launch_backtrace(Runtime* rt, const BatchD& b, int maxn);
+
+struct ScoreArgs {
+    int nitems_per_job;        // M
+    int ncolmax;               // max new columns of any edit
+    int ws;                    // scoring_width
+    const int* m_start;        // [M]
+    const int* m_mlen;         // [M] len(mut)
+    const int* m_cm;           // [M] states of the edited sequence
+    const int* m_ncol;         // [M] new columns actually produced
+    const int* m_skip;         // [M] 1: edit skipped (start > len)
+    const int* m_states;       // [M][ncolmax] states of the new columns
+    const int* m_oldidx;       // [M] index into the unique-r0 list
+    const int* r0;             // [nr0] unique max(start-3,1) values
+    int nr0;
+    double* old;               // [njobs][nr0]
+    double* delta;             // [njobs][M]
+    double* score;             // [M]
+};
+// cls_items[k]: device list of edit indices whose new-column count fits 8 << k lanes (k = 3: chunked, any size)
+int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* const cls_items[4], const int cls_count[4]);
+int launch_begin(Runtime* rt, const BatchD& b);
+
+// Smith-Waterman (ps_sw.hip)
+int sw_device(Runtime* rt, const std::string& s1, const std::string& s2, int* score, double* accuracy,
+              std::vector<int>* inds1, std::vector<int>* inds2);
+
+// Viterbi (ps_viterbi.hip)
+struct VitStepH { int refind; };
+int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin /*[T][E][4]: lvl, sd, logsd, present*/,
+                   const double* d_model, int nkeep, double skip, double stay, double mmin, double mmax,
+                   const double* h_rand /*[nkeep][T]*/, std::vector<std::vector<int>>* paths);
+
+void prof_begin(Runtime* rt);
+void prof_end(Runtime* rt, const char* name, double alg_bytes);
+
+}  // namespace ps
+
+#endif

@@ -1,0 +1,736 @@
+// ps_kernels.hip — gfx950 kernels for the banded event<->sequence DP and the edit scoring.
+//
+// Reference behaviour being reproduced (file:line under the reference tree):
+//   updaterefs / getrefstate      cpp/EventData.h:110-183
+//   fillColumn / fillColumnBack   cpp/Alignment.cpp:111-274 / :280-444
+//   backtrace                     cpp/Alignment.cpp:516-624
+//   scoreMutation / columnMax     cpp/Alignment.cpp:447-512, cpp/Alignment.h:181-214
+//   ScoreMutations accumulation   cpp/MakeMutations.cpp:23-69
+//
+// Everything is FP64 and compiled with -ffp-contract=off: each cell is computed with the
+// reference's operation order, so results are bit-identical to the CPU path (logs / pow are
+// taken on the host with the same libm the reference uses).
+//
+// Execution model.  A DP cell (i, j) (level i, state column j) lives on anti-diagonal s = i + j.
+// Storage is skewed: REC[s][i mod P].  One workgroup of P lanes owns one alignment and sweeps
+// s = 2 .. n0 + C; lane `slot` owns the row i == slot (mod P) that is inside the band on that
+// anti-diagonal (the band's footprint on one anti-diagonal is a contiguous run of at most
+// 2W + 1 <= P rows, because the band centre is a monotone function of the column).  Cell (i, j)
+// needs (i, j-1) = the lane's own previous value, (i-1, j) = the neighbour lane's previous
+// value (DPP wave shift; LDS hand-off across waves) and (i-1, j-1) = what the neighbour handed
+// over one step earlier.  Emission log-densities (three FP64 divisions each) do not take part in
+// the recurrence and are produced by a separate, chip-wide pass straight into REC.
+#include "ps_internal.h"
+
+namespace ps {
+
+enum : unsigned { F_ACT = 1, F_VL = 2, F_VD = 4, F_TOP = 8, F_INV = 16, F_BLANK = 32 };
+enum : unsigned { M_SKIP = 0, M_MATCH = 1, M_INSERT = 2, M_IGNORE = 3, M_STAY = 4, M_EXTEND = 5, M_IMPL = 255 };
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// std::lower_bound(double*, int) exactly as libstdc++ walks it (cpp/EventData.h:178)
+__device__ int lower_bound_d(const double* __restrict__ a, int n, int v) {
+    int first = 0, len = n;
+    const double dv = (double)v;
+    while (len > 0) {
+        int half = len >> 1;
+        int mid = first + half;
+        if (a[mid] < dv) { first = mid + 1; len = len - half - 1; } else { len = half; }
+    }
+    return first;
+}
+
+// band of column `col` (1-based) in direction dir; lb = raw lower_bound table (-1 = empty ref_index)
+__device__ __forceinline__ void band_of(const int* __restrict__ lb, int dir, int col, int C, int n0, int W, int& i0, int& i1) {
+    int c;
+    if (dir == 0) { int v = lb[col]; c = v < 0 ? 1 : v; }
+    else { int v = lb[C - col + 1]; c = v < 0 ? 1 : n0 - v + 1; }
+    c = clampi(c, 1, n0);
+    i0 = max(1, c - W);
+    i1 = min(n0, c + W);
+}
+
+__device__ __forceinline__ int slot_of(int i, int P) { return i % P; }
+
+// emission log-density; cpp/AlignUtil.h:34-38,48-53 + cpp/Alignment.cpp:169-173
+struct ModelRow { double mu, sg, lsg, sm, lam, llam; };
+__device__ __forceinline__ double emission(const ModelRow& m, double x, double sd, double lsd, double log2pi, double off) {
+    double d = (x - m.mu) / m.sg;
+    double l = -0.5 * (d * d + log2pi) - m.lsg;
+    double e = (sd - m.sm) / m.sm;
+    double g = 0.5 * (m.llam - 3 * lsd - log2pi - e * e * m.lam / sd);
+    l += g;
+    l += off;
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// updaterefs: ref_align -> ref_index, refstart, refend   (cpp/EventData.h:110-169)
+// one 256-thread block per job; each thread owns a contiguous chunk of levels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_updaterefs(BatchD b) {
+    const JobD& J = b.jobs[blockIdx.x];
+    JobOut* O = b.out + blockIdx.x;
+    const int n = J.n0, tid = threadIdx.x;
+    const double* __restrict__ ra = J.ra;
+    double* __restrict__ ri = J.ri;
+    __shared__ int s_first[256], s_last[256];
+    const int chunk = (n + 255) / 256;
+    const int t0 = min(n, tid * chunk), t1 = min(n, t0 + chunk);
+    int first = 0x7fffffff, last = -1;
+    for (int t = t0; t < t1; t++)
+        if (ra[t] > 0) { if (first == 0x7fffffff) first = t; last = t; }
+    s_first[tid] = first; s_last[tid] = last;
+    __syncthreads();
+    int a0 = 0x7fffffff, a1 = -1, prev = -1, next = 0x7fffffff;
+    for (int k = 0; k < 256; k++) {
+        a0 = min(a0, s_first[k]); a1 = max(a1, s_last[k]);
+        if (k < tid) prev = max(prev, s_last[k]);
+        if (k > tid) next = min(next, s_first[k]);
+    }
+    if (a1 < 0) {
+        if (tid == 0) { O->has_index = 0; O->refstart = -1; O->refend = -1; }
+        return;
+    }
+    if (tid == 0) { O->has_index = 1; O->refstart = (int)ra[a0]; O->refend = (int)ra[a1]; }
+    const double slope = (ra[a1] - ra[a0]) / (double)(a1 - a0);
+    const double icpt = ra[a0] - slope * (double)a0;
+    int lastal = prev;
+    for (int t = t0; t < t1; t++) {
+        const double v = ra[t];
+        if (t < a0 || t > a1) {
+            ri[t] = slope * (double)t + icpt;
+        } else if (v > 0) {
+            ri[t] = v;
+            lastal = t;
+        } else {
+            // inside [a0, a1], not aligned: interpolate between neighbours unless the left anchor is level 0 (sic)
+            int nx = t + 1;
+            while (nx < t1 && !(ra[nx] > 0)) nx++;
+            if (nx >= t1) nx = next;
+            if (lastal > 0) {
+                const double mm = (ra[nx] - ra[lastal]) / (double)(nx - lastal);
+                ri[t] = mm * (double)(t - lastal) + ra[lastal];
+            } else {
+                ri[t] = v;
+            }
+        }
+    }
+}
+
+// lb[j] = getrefstate(j) for j = 0 .. lbn-1 (or -1 when ref_index is empty)
+__global__ void k_lb(BatchD b, int which) {
+    const JobD& J = b.jobs[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J.lbn) return;
+    int* lb = b.lb + (which ? J.lbn_off : J.lb_off);
+    lb[j] = b.out[blockIdx.y].has_index ? lower_bound_d(J.ri, J.n0, j) : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lo[s]: lowest in-band row on anti-diagonal s  (-1: none).  The rows of s are s - j for the
+// columns j with i0(j) + j <= s <= i1(j) + j, a contiguous column range; lo = s - jhi.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lo(BatchD b, int ndir) {
+    const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
+    const JobD& J = b.jobs[job];
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= J.S || b.out[job].inert) return;
+    const int* lb = b.lb + J.lb_off;
+    int* LO = b.lo + J.lo_off[dir];
+    int res = -1;
+    if (J.C >= 1) {
+        int i0, i1;
+        band_of(lb, dir, 1, J.C, J.n0, J.W, i0, i1);
+        if (i0 + 1 <= s) {
+            int lo = 1, hi = J.C;  // invariant: f(lo) <= s
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                band_of(lb, dir, mid, J.C, J.n0, J.W, i0, i1);
+                if ((int64_t)i0 + mid <= s) lo = mid; else hi = mid - 1;
+            }
+            res = (int)(s - lo);
+        }
+    }
+    LO[s] = res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// emission pass: for every (s, slot) write REC.x = emission (or 0) and FLG = band flags
+// grid (nblk, njobs*ndir), block 256; the event's 48 KB model is staged in LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
+    __shared__ double s_model[6 * NS];
+    const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
+    const JobD& J = b.jobs[job];
+    if (b.out[job].inert) return;
+    const double* gm = b.model + (size_t)J.ev * 6 * NS;
+    for (int k = threadIdx.x; k < 6 * NS; k += 256) s_model[k] = gm[k];
+    __syncthreads();
+    const int P = J.P, n0 = J.n0, C = J.C, W = J.W;
+    const int* __restrict__ lb = b.lb + J.lb_off;
+    const int* __restrict__ LO = b.lo + J.lo_off[dir];
+    const int* __restrict__ st = b.states + J.st_off;
+    const double* __restrict__ mean = b.mean + J.lev_off;
+    const double* __restrict__ stdv = b.stdv + J.lev_off;
+    const double* __restrict__ lsdv = b.logstdv + J.lev_off;
+    double2* __restrict__ rec = b.rec + J.mat_off[dir];
+    unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
+    const int64_t ncell = J.S * P;
+    for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < ncell; cell += (int64_t)gridDim.x * 256) {
+        const int s = (int)(cell / P), slot = (int)(cell - (int64_t)s * P);
+        unsigned f = 0;
+        double e = 0.0;
+        const int lo = LO[s];
+        if (lo >= 0) {
+            int d = (slot - lo % P + P) % P;
+            const int i = lo + d, j = s - i;
+            if (i <= n0 && j >= 1 && j <= C) {
+                int i0, i1;
+                band_of(lb, dir, j, C, n0, W, i0, i1);
+                if (i >= i0 && i <= i1) {
+                    f = F_ACT;
+                    int p0, p1;
+                    if (j == 1) { p0 = 0; p1 = n0; f |= F_BLANK; }
+                    else band_of(lb, dir, j - 1, C, n0, W, p0, p1);
+                    if (i >= p0 && i <= p1) f |= F_VL;
+                    if (i > p0 && i <= p1) f |= F_VD;
+                    if (i == i0) f |= F_TOP;
+                    const int state = st[dir == 0 ? j - 1 : C - j];
+                    if (state < 0) {
+                        f |= F_INV;
+                    } else {
+                        ModelRow m = {s_model[state], s_model[NS + state], s_model[2 * NS + state],
+                                      s_model[3 * NS + state], s_model[4 * NS + state], s_model[5 * NS + state]};
+                        // forward reads level i-1 but log_stdv[n0-i] (sic, cpp/Alignment.cpp:171-172); backward reads level n0-i
+                        const int tv = dir == 0 ? i - 1 : n0 - i;
+                        e = emission(m, mean[tv], stdv[tv], lsdv[n0 - i], b.log2pi, b.lik_offset);
+                    }
+                }
+            }
+        }
+        rec[cell] = make_double2(e, 0.0);
+        flg[cell] = (unsigned short)f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// recurrence pass: one workgroup (P lanes) per (job, direction)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_shr1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int PF = 4;  // anti-diagonals of emission / flag prefetch kept in registers
+
+template <int DIR>
+__device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, double (*xch)[16][4]) {
+    const int P = J.P, slot = threadIdx.x, lane = slot & 63, wave = slot >> 6, NW = P >> 6;
+    const int wprev = (wave + NW - 1) % NW;
+    const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
+    double2* __restrict__ rec = b.rec + J.mat_off[DIR];
+    unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR];
+    const int64_t S = J.S;
+    double cm = 0.0, cs = 0.0, co = 0.0;   // this lane's latest main / stay / emission
+    double upm = 0.0, upo = 0.0;           // what the upper neighbour handed over one step ago
+    int par = 0;
+    if (lane == 63) { xch[0][wave][0] = 0.0; xch[0][wave][1] = 0.0; xch[0][wave][2] = 0.0; }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    double e_cur[PF], e_nxt[PF];
+    unsigned f_cur[PF], f_nxt[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+        const int64_t s = 2 + u;
+        e_cur[u] = s < S ? rec[s * P + slot].x : 0.0;
+        f_cur[u] = s < S ? flg[s * P + slot] : 0u;
+    }
+    for (int64_t s0 = 2; s0 < S; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int64_t s = s0 + PF + u;
+            e_nxt[u] = s < S ? rec[s * P + slot].x : 0.0;
+            f_nxt[u] = s < S ? flg[s * P + slot] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int64_t s = s0 + u;
+            if (s < S) {  // uniform over the workgroup
+                const unsigned f = f_cur[u];
+                double um = wave_shr1(cm), us = wave_shr1(cs), uo = 0.0;
+                if (DIR) uo = wave_shr1(co);
+                if (lane == 0) { um = xch[par][wprev][0]; us = xch[par][wprev][1]; if (DIR) uo = xch[par][wprev][2]; }
+                double D = upm, L = cm;
+                const double pobs = upo;
+                upm = um;
+                if (DIR) upo = uo;
+                if (f & F_ACT) {
+                    double nm = 0.0, ns = 0.0;
+                    unsigned sm = 0, ss = 0;
+                    double o = 0.0;
+                    if (!(f & F_INV)) {
+                        o = e_cur[u];
+                        double po = pobs;
+                        if (f & F_BLANK) { L = 0.0; D = 0.0; po = 0.0; }
+                        const bool vl = f & F_VL, vd = f & F_VD;
+                        const double cSKIP = vl ? L + lsk : lsk;
+                        const unsigned kSKIP = vl ? M_SKIP : M_IMPL;
+                        double cMATCH;
+                        if (DIR == 0) cMATCH = vd ? D + o : o; else cMATCH = vd ? D + po : 0.0;
+                        const unsigned kMATCH = vd ? M_MATCH : M_IMPL;
+                        const double cIGN = vd ? D + lin : 0.0;
+                        double cSTAY = -BIG, cEXT = -BIG, cINS = 0.0;
+                        if (f & F_TOP) {
+                            ns = -BIG;
+                        } else {
+                            const double eo = DIR == 0 ? o : uo;
+                            cSTAY = um + eo + lst;
+                            cINS = um + lin;
+                            cEXT = us + eo + lex;
+                        }
+                        if (cSTAY > ns) { ns = cSTAY; ss = M_STAY; }
+                        if (cEXT > ns) { ns = cEXT; ss = M_EXTEND; }
+                        if (cSKIP > nm) { nm = cSKIP; sm = kSKIP; }
+                        if (cMATCH > nm) { nm = cMATCH; sm = kMATCH; }
+                        if (cINS > nm) { nm = cINS; sm = M_INSERT; }
+                        if (cIGN > nm) { nm = cIGN; sm = M_IGNORE; }
+                        if (ns > nm) { nm = ns; sm = M_STAY; }
+                    }
+                    cm = nm; cs = ns; co = o;
+                    rec[s * P + slot] = make_double2(nm, ns);
+                    flg[s * P + slot] = (unsigned short)(sm | (ss << 8));
+                }
+                if (lane == 63) { xch[par ^ 1][wave][0] = cm; xch[par ^ 1][wave][1] = cs; if (DIR) xch[par ^ 1][wave][2] = co; }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                par ^= 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) { e_cur[u] = e_nxt[u]; f_cur[u] = f_nxt[u]; }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_recur(BatchD b, int ndir) {
+    __shared__ double xch[2][16][4];
+    const int jd = blockIdx.x, job = jd / ndir, dir = jd % ndir;
+    const JobD& J = b.jobs[job];
+    if (b.out[job].inert) return;
+    if (dir == 0) recur_body<0>(b, J, xch); else recur_body<1>(b, J, xch);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-column max of the main matrix (-> MaxInfo per column) ; grid (maxC, njobs*ndir), block 64
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_colstats(BatchD b, int ndir) {
+    const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
+    const JobD& J = b.jobs[job];
+    const int c = blockIdx.x + 1;
+    if (c > J.C) return;
+    double best = 0.0;
+    int brow = 0;
+    if (!b.out[job].inert) {
+        const int* lb = b.lb + J.lb_off;
+        const double2* __restrict__ rec = b.rec + J.mat_off[dir];
+        int i0, i1;
+        band_of(lb, dir, c, J.C, J.n0, J.W, i0, i1);
+        double v = 0.0; int r = 0x7fffffff;
+        for (int i = i0 + (int)threadIdx.x; i <= i1; i += 64) {
+            const double x = rec[(int64_t)(i + c) * J.P + slot_of(i, J.P)].x;
+            if (x > v) { v = x; r = i; }
+        }
+        for (int off = 32; off; off >>= 1) {
+            const double ov = __shfl_xor(v, off);
+            const int orow = __shfl_xor(r, off);
+            if (ov > v || (ov == v && orow < r)) { v = ov; r = orow; }
+        }
+        best = v; brow = (r == 0x7fffffff) ? 0 : r;
+    }
+    if (threadIdx.x == 0) { b.cmax[J.col_off[dir] + c] = best; b.cmaxrow[J.col_off[dir] + c] = brow; }
+}
+
+// prefix max over columns + (fwd) the first cell achieving the global max ; grid njobs*ndir, block 64
+__global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
+    const int jd = blockIdx.x, job = jd / ndir, dir = jd % ndir;
+    const JobD& J = b.jobs[job];
+    const double* cmax = b.cmax + J.col_off[dir];
+    double* pm = b.pm + J.col_off[dir];
+    const int lane = threadIdx.x;
+    double carry = 0.0;
+    if (lane == 0) pm[0] = 0.0;
+    for (int c0 = 1; c0 <= J.C; c0 += 64) {
+        const int c = c0 + lane;
+        double v = c <= J.C ? cmax[c] : 0.0;
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(v, off);
+            if (lane >= off && o > v) v = o;
+        }
+        if (carry > v) v = carry;
+        if (c <= J.C) pm[c] = v;
+        carry = __shfl(v, 63);
+    }
+    if (dir == 0) {
+        const double best = carry;
+        int bj = 0x7fffffff;
+        if (best > 0.0)
+            for (int c = 1 + lane; c <= J.C; c += 64)
+                if (cmax[c] == best) { bj = c; break; }
+        for (int off = 32; off; off >>= 1) bj = min(bj, __shfl_xor(bj, off));
+        if (lane == 0) {
+            JobOut* O = b.out + job;
+            O->best = best;
+            if (best > 0.0) { O->bj = bj; O->bi = b.cmaxrow[J.col_off[0] + bj]; }
+            else { O->bj = 0; O->bi = 0; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backtrace (cpp/Alignment.cpp:516-624): one wave per job, 16x16 tiles staged in LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_backtrace(BatchD b) {
+    const JobD& J = b.jobs[blockIdx.x];
+    if (b.out[blockIdx.x].inert) return;  // stripe_width == 0: the event is left untouched
+    const JobOut O = b.out[blockIdx.x];
+    const int lane = threadIdx.x, P = J.P, n0 = J.n0;
+    double* __restrict__ ra = J.ra;
+    double* __restrict__ rl = J.rl;
+    for (int t = lane; t < n0; t += 64) { ra[t] = 0.0; rl[t] = 0.0; }
+    __syncthreads();
+    const double2* __restrict__ rec = b.rec + J.mat_off[0];
+    const unsigned short* __restrict__ flg = b.flg + J.mat_off[0];
+    __shared__ double t_main[16][17], t_stay[16][17];
+    __shared__ unsigned short t_step[16][17];
+    int i = O.bi, j = O.bj, arr = 0;
+    bool done = (i <= 0);
+    while (!done) {
+        const int ti = i, tj = j;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int idx = lane + 64 * q, a = idx >> 4, c = idx & 15;
+            const int r = ti - a, col = tj - c;
+            double m = 0.0, s = 0.0; unsigned short st = 0;
+            if (r >= 1 && col >= 1) {
+                const int64_t at = (int64_t)(r + col) * P + slot_of(r, P);
+                const double2 v = rec[at];
+                m = v.x; s = v.y; st = flg[at];
+            }
+            t_main[a][c] = m; t_stay[a][c] = s; t_step[a][c] = st;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            while (true) {
+                const int a = ti - i, c = tj - j;
+                if (i <= 0) { done = true; break; }
+                if (a > 15 || c > 15) break;  // next tile
+                const unsigned stp = t_step[a][c];
+                const unsigned st = arr ? (stp >> 8) : (stp & 255u);
+                const double sc = arr ? t_stay[a][c] : t_main[a][c];
+                if (sc <= 0.0) { done = true; break; }
+                if (st == M_SKIP) { j--; }
+                else if (st == M_MATCH) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; j--; }
+                else if (st == M_IGNORE) { ra[i - 1] = -1.0; rl[i - 1] = sc; i--; j--; }
+                else if (st == M_INSERT) { ra[i - 1] = -1.0; rl[i - 1] = sc; i--; }
+                else if (st == M_STAY) {
+                    if (arr == 1) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
+                    arr = 1 - arr;
+                }
+                else if (st == M_EXTEND) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
+                else { done = true; break; }
+            }
+        }
+        i = __shfl(i, 0); j = __shfl(j, 0); arr = __shfl(arr, 0);
+        done = __shfl((int)done, 0) != 0;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// columnMax(raf, rab) on the filled matrices (cpp/Alignment.h:181-214); cooperative over `nl` lanes
+// Only rows where both columns are in band can exceed the two running maxima (stay <= main <= max).
+// ------------------------------------------------------------------------------------------------
+__device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, int lane, int nl) {
+    const int C = J.C, n0 = J.n0, P = J.P;
+    if ((unsigned)raf >= (unsigned)(C + 1)) raf = C;
+    if ((unsigned)rab >= (unsigned)(C + 1)) rab = C;
+    const int* lb = b.lb + J.lb_off;
+    int f0 = 0, f1 = n0, b0 = 0, b1 = n0;
+    if (raf > 0) band_of(lb, 0, raf, C, n0, J.W, f0, f1);
+    if (rab > 0) band_of(lb, 1, rab, C, n0, J.W, b0, b1);
+    const double2* __restrict__ rf = b.rec + J.mat_off[0];
+    const double2* __restrict__ rb = b.rec + J.mat_off[1];
+    // jb = n0 - jf + 1 in [b0, b1]  <=>  jf in [n0 + 1 - b1, n0 + 1 - b0]
+    const int lo = max(max(1, f0), n0 + 1 - b1), hi = min(min(n0, f1), n0 + 1 - b0);
+    double sm = 0.0;
+    for (int jf = lo + lane; jf <= hi; jf += nl) {
+        const int jb = n0 - jf + 1;
+        double2 fv = make_double2(0.0, 0.0), bv = make_double2(0.0, 0.0);
+        if (raf > 0) fv = rf[(int64_t)(jf + raf) * P + slot_of(jf, P)];
+        if (rab > 0) bv = rb[(int64_t)(jb + rab) * P + slot_of(jb, P)];
+        sm = fmax(sm, fmax(fv.x + bv.x, fv.y + bv.y));
+    }
+    for (int off = 1; off < nl; off <<= 1) sm = fmax(sm, __shfl_xor(sm, off));
+    sm = fmax(sm, b.pm[J.col_off[0] + raf]);
+    sm = fmax(sm, b.pm[J.col_off[1] + rab]);
+    return sm;
+}
+
+// old score for each distinct r0 = max(start - 3, 1) ; grid (nr0, njobs), block 64
+__global__ __launch_bounds__(64) void k_old(BatchD b, ScoreArgs a) {
+    const JobD& J = b.jobs[blockIdx.y];
+    if (b.out[blockIdx.y].inert) return;
+    const int r0 = a.r0[blockIdx.x];
+    const double v = colmax_pair(b, J, r0, J.C - r0 + 1, threadIdx.x, 64);
+    if (threadIdx.x == 0) a.old[(size_t)blockIdx.y * a.nr0 + blockIdx.x] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scoreMutation (cpp/Alignment.cpp:447-512): G lanes per (event, edit) item, lane = new column,
+// rows stream through the group systolically (lane c works on row  base + t - c  at step t).
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int* __restrict__ items, int nitems) {
+    constexpr int IPW = 64 / G;
+    __shared__ double s_carry[(G == 64) ? 4 * 1024 : 1];   // last column of a 64-column chunk, per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / G, c = lane % G;
+    const int job = blockIdx.y;
+    const JobD& J = b.jobs[job];
+    const int it = (blockIdx.x * 4 + wave) * IPW + g;
+    const bool have = it < nitems;
+    const int m = have ? items[it] : 0;
+    const int n0 = J.n0, C = J.C, P = J.P, WS = a.ws;
+    const bool live = have && !b.out[job].inert && !a.m_skip[m];
+    if (__ballot(live) == 0ull) {
+        if (have && c == 0) a.delta[(size_t)job * a.nitems_per_job + m] = 0.0;
+        return;
+    }
+    const int start = a.m_start[m], mlen = a.m_mlen[m], Cm = a.m_cm[m], ncol = live ? a.m_ncol[m] : 0;
+    const int sidx = max(start - 4, 0);
+    const int tcol = min(start + mlen + 1, sidx + ncol);   // target column (== sidx: the spliced copy itself)
+    const int trel = tcol - sidx - 1;                      // 0-based new-column index of the target (-1: copy)
+    int backind = Cm - tcol + 1;
+    if ((unsigned)backind >= (unsigned)(C + 1)) backind = C;
+    const int* __restrict__ lbf = b.lb + J.lb_off;    // tables the fills were made with
+    const int* __restrict__ lbn = b.lb + J.lbn_off;   // after the backtrace: centres of the new columns
+    const double* __restrict__ mean = b.mean + J.lev_off;
+    const double* __restrict__ stdv = b.stdv + J.lev_off;
+    const double* __restrict__ lsdv = b.logstdv + J.lev_off;
+    const double2* __restrict__ rf = b.rec + J.mat_off[0];
+    const double2* __restrict__ rb = b.rec + J.mat_off[1];
+    const double* gm = b.model + (size_t)J.ev * 6 * NS;
+    const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
+
+    // band of the back column the target is combined with
+    int bb0 = 0, bb1 = n0;
+    if (backind > 0) band_of(lbf, 1, backind, C, n0, J.W, bb0, bb1);
+
+    double fmaxv = live ? b.pm[J.col_off[0] + sidx] : 0.0;   // running MaxInfo score, carried from the spliced column
+    double tm = 0.0;                                          // max over rows of fwd + back on the target column
+    // previous column of the first chunk: the original forward column sidx (blank column 0 if sidx == 0)
+    int pc0 = 0, pc1 = n0;
+    if (live && sidx > 0) band_of(lbf, 0, sidx, C, n0, J.W, pc0, pc1);
+    double* carry = s_carry + wave * 1024;
+
+    const int nchunk = (ncol + G - 1) / G;
+    int nchunk_w = nchunk;
+    for (int off = 1; off < 64; off <<= 1) nchunk_w = max(nchunk_w, __shfl_xor(nchunk_w, off));
+    for (int ch = 0; ch < nchunk_w; ch++) {
+        const int cc = ch * G + c;                 // new-column index of this lane
+        const bool mine = live && cc < ncol;
+        const int jc = sidx + 1 + cc;              // column number in the edited sequence
+        int i0 = 1, i1 = 0, state = -1;
+        if (mine) {
+            const int v = lbn[jc];
+            const int ce = clampi(v < 0 ? 1 : v, 1, n0);
+            i0 = max(1, ce - WS); i1 = min(n0, ce + WS);
+            state = a.m_states[(size_t)m * a.ncolmax + cc];
+        }
+        ModelRow mr = {0, 1, 0, 1, 0, 0};
+        if (state >= 0) mr = {gm[state], gm[NS + state], gm[2 * NS + state], gm[3 * NS + state], gm[4 * NS + state], gm[5 * NS + state]};
+        // band of the column to the left
+        int p0 = __shfl_up(i0, 1), p1 = __shfl_up(i1, 1);
+        if (c == 0) { p0 = pc0; p1 = pc1; }
+        const int base = __shfl(i0, g * G);                       // first row of the chunk's first column
+        int lastcol = min(ncol - ch * G, G) - 1;                   // lanes 0..lastcol are in use
+        int span = mine ? (i1 - base) + c : -1;
+        for (int off = 1; off < 64; off <<= 1) span = max(span, __shfl_xor(span, off));
+        double cm = 0.0, cs = 0.0, colmax = 0.0, lprev = 0.0;
+        const bool is_t = mine && cc == trel;
+        for (int t = -1; t <= span; t++) {
+            const int i = base + t - c;
+            // value of (i, jc-1): matrix / carried chunk column for lane 0, left neighbour otherwise
+            double L = wave_shr1(cm);
+            if (c == 0) {
+                L = 0.0;
+                if (mine && i >= p0 && i <= p1 && i >= 1) {
+                    if (ch > 0) L = carry[i - p0];
+                    else if (sidx > 0) L = rf[(int64_t)(i + sidx) * P + slot_of(i, P)].x;
+                }
+            }
+            const double D = lprev;
+            lprev = L;
+            if (mine && i >= i0 && i <= i1) {
+                double nm = 0.0, ns = 0.0;
+                if (state >= 0) {
+                    const double o = emission(mr, mean[i - 1], stdv[i - 1], lsdv[n0 - i], b.log2pi, b.lik_offset);
+                    const bool vl = i >= p0 && i <= p1, vd = i > p0 && i <= p1;
+                    const double cSKIP = vl ? L + lsk : lsk;
+                    const double cMATCH = vd ? D + o : o;
+                    const double cIGN = vd ? D + lin : 0.0;
+                    double cSTAY = -BIG, cEXT = -BIG, cINS = 0.0;
+                    if (i == i0) ns = -BIG;
+                    else { cSTAY = cm + o + lst; cINS = cm + lin; cEXT = cs + o + lex; }
+                    if (cSTAY > ns) ns = cSTAY;
+                    if (cEXT > ns) ns = cEXT;
+                    if (cSKIP > nm) nm = cSKIP;
+                    if (cMATCH > nm) nm = cMATCH;
+                    if (cINS > nm) nm = cINS;
+                    if (cIGN > nm) nm = cIGN;
+                    if (ns > nm) nm = ns;
+                }
+                cm = nm; cs = ns;
+                if (nm > colmax) colmax = nm;
+                if (is_t) {
+                    const int jb = n0 - i + 1;
+                    if (jb >= bb0 && jb <= bb1) {
+                        double2 bv = make_double2(0.0, 0.0);
+                        if (backind > 0) bv = rb[(int64_t)(jb + backind) * P + slot_of(jb, P)];
+                        tm = fmax(tm, fmax(nm + bv.x, ns + bv.y));
+                    }
+                }
+                if (G == 64 && c == lastcol && ch + 1 < nchunk) carry[i - i0] = nm;
+            }
+        }
+        // MaxInfo: max over the new columns up to and including the target
+        double cmx = (mine && cc <= trel) ? colmax : 0.0;
+        for (int off = 1; off < G; off <<= 1) cmx = fmax(cmx, __shfl_xor(cmx, off));
+        fmaxv = fmax(fmaxv, cmx);
+        // next chunk continues from this chunk's last column
+        pc0 = __shfl(i0, g * G + max(lastcol, 0)); pc1 = __shfl(i1, g * G + max(lastcol, 0));
+        __builtin_amdgcn_wave_barrier();
+    }
+    // gather the target lane's row maximum
+    double tmx = tm;
+    for (int off = 1; off < G; off <<= 1) tmx = fmax(tmx, __shfl_xor(tmx, off));
+    double now;
+    if (trel < 0) {
+        now = !live ? 0.0 : colmax_pair(b, J, sidx, backind, c, G);   // no new column: the spliced copy is the target
+    } else {
+        now = fmax(0.0, tmx);
+        now = fmax(now, fmaxv);
+        now = fmax(now, b.pm[J.col_off[1] + backind]);
+    }
+    if (have && c == 0) {
+        double d = 0.0;
+        if (live) {
+            const double old = a.old[(size_t)job * a.nr0 + a.m_oldidx[m]];
+            d = now - old;
+        }
+        a.delta[(size_t)job * a.nitems_per_job + m] = d;
+    }
+}
+
+// score[m] = -1e-6 + sum over events in order (cpp/AlignUtil.h:86, cpp/MakeMutations.cpp:51)
+__global__ void k_reduce(ScoreArgs a, int njobs) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.nitems_per_job) return;
+    double s = -1e-6;
+    for (int e = 0; e < njobs; e++) s += a.delta[(size_t)e * a.nitems_per_job + m];
+    a.score[m] = s;
+}
+
+// latch the reference's "stripe_width == 0" decision (cpp/Alignment.cpp:51-59) for this API call
+__global__ void k_begin(BatchD b) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= b.njobs) return;
+    b.out[j].inert = (b.jobs[j].force_inert || !b.out[j].has_index) ? 1 : 0;
+    b.out[j].best = 0.0; b.out[j].bi = 0; b.out[j].bj = 0;
+}
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+#define PS_LAUNCH_CHECK() PS_HIP(hipGetLastError())
+
+int launch_updaterefs(Runtime* rt, const BatchD& b) {
+    if (!b.njobs) return PS_OK;
+    hipLaunchKernelGGL(k_updaterefs, dim3(b.njobs), dim3(256), 0, rt->stream, b);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int launch_lb(Runtime* rt, const BatchD& b, int which, int maxlbn) {
+    if (!b.njobs) return PS_OK;
+    if (maxlbn <= 0) return fail(PS_ERR_BAD_ARG, "launch_lb: size");
+    hipLaunchKernelGGL(k_lb, dim3((maxlbn + 255) / 256, b.njobs), dim3(256), 0, rt->stream, b, which);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P) {
+    if (!b.njobs) return PS_OK;
+    hipLaunchKernelGGL(k_lo, dim3((unsigned)((maxS + 255) / 256), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
+    PS_LAUNCH_CHECK();
+    int nblk = (int)std::min<int64_t>((maxS * P + 256 * 16 - 1) / (256 * 16), std::max(16, 4096 / (b.njobs * ndir)));
+    nblk = std::max(nblk, 1);
+    hipLaunchKernelGGL(k_emis, dim3(nblk, b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
+    PS_LAUNCH_CHECK();
+    prof_begin(rt);
+    hipLaunchKernelGGL(k_recur, dim3(b.njobs * ndir), dim3(P), 0, rt->stream, b, ndir);
+    PS_LAUNCH_CHECK();
+    prof_end(rt, "fill", 0.0);
+    return PS_OK;
+}
+
+int launch_colstats(Runtime* rt, const BatchD& b, int ndir, int maxC) {
+    if (!b.njobs || maxC < 1) return PS_OK;
+    hipLaunchKernelGGL(k_colstats, dim3(maxC, b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
+    PS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_prefix, dim3(b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int launch_backtrace(Runtime* rt, const BatchD& b, int) {
+    if (!b.njobs) return PS_OK;
+    hipLaunchKernelGGL(k_backtrace, dim3(b.njobs), dim3(64), 0, rt->stream, b);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int launch_begin(Runtime* rt, const BatchD& b) {
+    if (!b.njobs) return PS_OK;
+    hipLaunchKernelGGL(k_begin, dim3((b.njobs + 63) / 64), dim3(64), 0, rt->stream, b);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* const cls_items[4], const int cls_count[4]) {
+    if (!b.njobs || !a.nitems_per_job) return PS_OK;
+    if (a.nr0 > 0) {
+        hipLaunchKernelGGL(k_old, dim3(a.nr0, b.njobs), dim3(64), 0, rt->stream, b, a);
+        PS_LAUNCH_CHECK();
+    }
+    prof_begin(rt);
+    for (int k = 0; k < 4; k++) {
+        const int n = cls_count[k];
+        if (!n) continue;
+        const int G = 8 << k, ipb = 4 * (64 / G);
+        dim3 grid((n + ipb - 1) / ipb, b.njobs), block(256);
+        if (k == 0) hipLaunchKernelGGL(k_score<8>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
+        else if (k == 1) hipLaunchKernelGGL(k_score<16>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
+        else if (k == 2) hipLaunchKernelGGL(k_score<32>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
+        else hipLaunchKernelGGL(k_score<64>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
+        PS_LAUNCH_CHECK();
+    }
+    prof_end(rt, "score", 0.0);
+    hipLaunchKernelGGL(k_reduce, dim3((a.nitems_per_job + 255) / 256), dim3(256), 0, rt->stream, a, b.njobs);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+}  // namespace ps
