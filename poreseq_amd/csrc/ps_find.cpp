@@ -1,5 +1,285 @@
+// ps_find.cpp — FindMutations (cpp/FindMutations.cpp:24-186), MapAlignments (cpp/EventUtil.cpp:12-55),
+// fillinds (cpp/swlib.cpp:342-365) and the host part of ViterbiMutate (cpp/Viterbi.cpp:239-426).
+// The alignments, Smith-Waterman matrices and the Viterbi recursion run on the GPU; what is left
+// here is the reference's list / index bookkeeping.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
 #include "ps_host.h"
+
 namespace ps {
-int find_mutations(Runtime*, Align*, const std::vector<std::string>&, std::vector<Mut>*) { return fail(PS_ERR_UNSUPPORTED, "find_mutations: not built yet"); }
-int viterbi_mutate(Runtime*, Align*, int, double, double, double, double, std::vector<std::string>*) { return fail(PS_ERR_UNSUPPORTED, "viterbi_mutate: not built yet"); }
+
+struct SwResult { int score = 0; double accuracy = 0; std::vector<int> a, b; };
+int sw_batch(Runtime* rt, const std::vector<std::pair<const std::string*, const std::string*>>& in, std::vector<SwResult>* out);
+
+static void fillinds(SwResult& al) {  // cpp/swlib.cpp:342-365
+    if (al.a.empty()) return;
+    int i1 = al.a[0], i2 = al.b[0];
+    for (size_t k = 0; k < al.a.size(); k++) {
+        if (al.a[k] > 0) i1 = al.a[k]; else al.a[k] = i1;
+        if (al.b[k] > 0) i2 = al.b[k]; else al.b[k] = i2;
+    }
 }
+
+static int argmax(const std::vector<double>& v) { return (int)(std::max_element(v.begin(), v.end()) - v.begin()); }
+
+int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds, std::vector<Mut>* out) {
+    out->clear();
+    const size_t L = a->bases.size();
+    // re-align to the current sequence, keeping per-base cumulative likelihoods (cpp/FindMutations.cpp:28-29)
+    std::vector<double> base(std::max<size_t>(L, 4) + 1, 0.0), sc(std::max(a->E, 1));
+    PS_TRY(score_alignments(rt, a, sc.data(), base.data()));
+    const int S = (int)seeds.size();
+    if (!S) return PS_OK;
+    // Smith-Waterman of the current sequence against every seed (MapAlignments, cpp/EventUtil.cpp:16)
+    std::vector<std::pair<const std::string*, const std::string*>> pairs;
+    for (const std::string& s : seeds) pairs.push_back({&a->bases, &s});
+    std::vector<SwResult> als;
+    PS_TRY(sw_batch(rt, pairs, &als));
+    for (SwResult& al : als) fillinds(al);
+    // seeds whose likelihood vector is not cached yet get (seed x event) alignment jobs
+    std::vector<int> need;
+    {
+        std::map<std::string, int> seen;
+        for (int k = 0; k < S; k++) {
+            if (!a->seqlikes[seeds[k]].empty()) continue;
+            if (seen.count(seeds[k])) continue;
+            seen[seeds[k]] = k;
+            need.push_back(k);
+        }
+    }
+    if (!need.empty() && a->E) {
+        PS_TRY(a->refs_to_host(rt));
+        std::vector<std::vector<int>> sstates(need.size());
+        for (size_t q = 0; q < need.size(); q++) sstates[q] = states_of(seeds[need[q]]);
+        // chunk the seeds so the DP matrices of one batch stay below ~48 GB
+        const int W = a->par.realign_width;
+        const int P = std::max(64, ((2 * W + 1 + 63) / 64) * 64);
+        size_t q0 = 0;
+        while (q0 < need.size()) {
+            size_t q1 = q0;
+            double bytes = 0;
+            while (q1 < need.size()) {
+                double add = 0;
+                for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + sstates[q1].size() + 1) * P * 18.0;
+                if (q1 > q0 && bytes + add > 48e9) break;
+                bytes += add; q1++;
+            }
+            const size_t ns = q1 - q0;
+            // remapped ref_align of every (seed, event) job, cpp/EventUtil.cpp:22-51
+            std::vector<double> h_ra((size_t)ns * a->ntot);
+            for (size_t q = q0; q < q1; q++) {
+                const SwResult& al = als[need[q]];
+                double* dst = h_ra.data() + (q - q0) * a->ntot;
+                for (int64_t t = 0; t < a->ntot; t++) {
+                    const int ra = (int)a->h_ra[t];
+                    double v = 0.0;
+                    if (!al.a.empty() && !(ra < al.a.front() || ra > al.a.back())) {
+                        const size_t k = std::lower_bound(al.a.begin(), al.a.end(), ra) - al.a.begin();
+                        v = k < al.b.size() ? (double)al.b[k] : 0.0;
+                    }
+                    dst[t] = v;
+                }
+            }
+            DBuf& rb = rt->buf("seed_refs");
+            PS_TRY(rb.ensure((size_t)3 * ns * std::max<int64_t>(a->ntot, 1) * sizeof(double)));
+            double* d_ra = rb.as<double>();
+            double* d_rl = d_ra + ns * a->ntot;
+            double* d_ri = d_rl + ns * a->ntot;
+            PS_HIP(hipMemcpyAsync(d_ra, h_ra.data(), h_ra.size() * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+            PS_HIP(hipMemsetAsync(d_rl, 0, ns * a->ntot * sizeof(double), rt->stream));
+            std::vector<JobSpec> specs;
+            for (size_t q = q0; q < q1; q++)
+                for (int e = 0; e < a->E; e++) {
+                    JobSpec s;
+                    s.ev = e; s.states = &sstates[q];
+                    const size_t o = (q - q0) * a->ntot + a->off[e];
+                    s.ra = d_ra + o; s.rl = d_rl + o; s.ri = d_ri + o;
+                    specs.push_back(s);
+                }
+            DBuf& ob = rt->buf("seed_out");
+            PS_TRY(ob.ensure(specs.size() * sizeof(JobOut)));
+            PS_HIP(hipMemsetAsync(ob.p, 0, specs.size() * sizeof(JobOut), rt->stream));
+            Batch b;
+            PS_TRY(b.build(rt, a, specs, 1, 0));
+            b.d.out = ob.as<JobOut>();
+            PS_TRY(launch_updaterefs(rt, b.d));  // MapAlignments ends with updaterefs (cpp/EventUtil.cpp:51)
+            PS_TRY(realign(rt, a, b, 0));
+            std::vector<double> r_ra(ns * a->ntot), r_rl(ns * a->ntot);
+            PS_HIP(hipMemcpyAsync(r_ra.data(), d_ra, r_ra.size() * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
+            PS_HIP(hipMemcpyAsync(r_rl.data(), d_rl, r_rl.size() * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
+            PS_HIP(hipStreamSynchronize(rt->stream));
+            for (size_t q = q0; q < q1; q++) {
+                const std::string& sd = seeds[need[q]];
+                std::vector<double> lk(std::max<size_t>(sd.size(), 4) + 1, 0.0);
+                for (int e = 0; e < a->E; e++) {
+                    const size_t o = (q - q0) * a->ntot + a->off[e];
+                    accumulate_likes(r_ra.data() + o, r_rl.data() + o, a->n[e], (int)sstates[q].size(), lk.data());
+                }
+                lk.resize(sd.size());
+                a->seqlikes[sd] = lk;
+            }
+            q0 = q1;
+        }
+    } else if (!need.empty()) {
+        for (int k : need) a->seqlikes[seeds[k]] = std::vector<double>(seeds[k].size(), 0.0);
+    }
+    // per seed: likelihood differences along the pairwise alignment -> clamped CUSUM (cpp/FindMutations.cpp:51-98)
+    std::vector<std::vector<double>> dl(S);
+    for (int k = 0; k < S; k++) {
+        SwResult& al = als[k];
+        const std::vector<double>& rl = a->seqlikes[seeds[k]];
+        for (size_t q = 0; q < al.a.size(); q++) { al.a[q] -= 2; al.b[q] -= 2; }
+        while (!al.a.empty() && (al.a[0] < 0 || al.b[0] < 0)) { al.a.erase(al.a.begin()); al.b.erase(al.b.begin()); }
+        const size_t n = al.a.size();
+        std::vector<double> x(n), y(n);
+        for (size_t q = 0; q < n; q++) {
+            x[q] = (size_t)al.a[q] < base.size() ? base[al.a[q]] : 0.0;
+            y[q] = (size_t)al.b[q] < rl.size() ? rl[al.b[q]] : 0.0;
+        }
+        for (size_t q = n; q-- > 1;) { x[q] -= x[q - 1]; y[q] -= y[q - 1]; }
+        if (n) { x[0] = 0; y[0] = 0; }
+        std::vector<double>& cs = dl[k];
+        cs.resize(n);
+        double run = 0;
+        for (size_t q = 0; q < n; q++) {
+            run += y[q] - x[q];
+            if (run < 0) run = 0;
+            cs[q] = run;
+            if (std::fabs(x[q] - y[q]) < 1e-5) cs[q] = 0;
+        }
+    }
+    // greedy extraction of candidate edits (cpp/FindMutations.cpp:111-183)
+    while (out->size() < L / 3) {
+        std::vector<double> top(S, 0.0);
+        for (int k = 0; k < S; k++) top[k] = dl[k].empty() ? 0.0 : dl[k][argmax(dl[k])];
+        const int w = argmax(top);
+        std::vector<double>& v = dl[w];
+        if (v.empty()) break;
+        const int ind = argmax(v);
+        if (v[ind] < 0.25) break;
+        int i1 = (int)(std::find(v.begin() + ind, v.end(), 0.0) - v.begin());
+        int i0 = -1;
+        for (int q = ind; q >= 0; q--) if (v[q] == 0) { i0 = q; break; }
+        if (i0 < 0) i0 = 0;
+        if (i1 < 0) i1 = 0;
+        if ((size_t)i0 >= v.size()) i0 = (int)v.size() - 1;
+        if ((size_t)i1 >= v.size()) i1 = (int)v.size() - 1;
+        const int s1 = als[w].a[i0], s2 = als[w].b[i0], e1 = als[w].a[ind], e2 = als[w].b[ind];
+        Mut m;
+        m.start = s1;
+        if ((size_t)s1 > a->bases.size() || (size_t)s2 > seeds[w].size())
+            return fail(PS_ERR_BAD_ARG, "FindMutations: alignment index outside the sequence");
+        m.orig = a->bases.substr(s1, (size_t)(e1 - s1));
+        m.mut = seeds[w].substr(s2, (size_t)(e2 - s2));
+        while (!m.orig.empty() && !m.mut.empty() && m.orig.front() == m.mut.front()) {
+            m.orig.erase(m.orig.begin()); m.mut.erase(m.mut.begin()); m.start++;
+        }
+        while (!m.orig.empty() && !m.mut.empty() && m.orig.back() == m.mut.back()) { m.orig.pop_back(); m.mut.pop_back(); }
+        if (!m.orig.empty() || !m.mut.empty()) out->push_back(m);
+        std::fill(v.begin() + i0, v.begin() + i1 + 1, 0.0);
+    }
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+inline int succ(int st, int k, int j) { return ((st << (2 * j)) & (NS - 1)) + k; }   // cpp/Viterbi.h:31-32
+inline char base_at(int st, int k) { return "ACGT"[3 & (st >> (2 * (4 - k)))]; }    // cpp/Viterbi.h:35-39
+
+// StatesToSequence, cpp/Viterbi.cpp:171-237
+static std::string path_to_bases(const std::vector<int>& st) {
+    std::string s;
+    int cur = st[0];
+    s.push_back(base_at(cur, 0));
+    for (size_t i = 1; i < st.size(); i++) {
+        if (cur == st[i]) continue;
+        bool hit = false;
+        for (int n = 1; n <= 4 && !hit; n++)
+            for (int k = 0; k < (1 << (2 * n)); k++)
+                if (succ(cur, k, n) == st[i]) {
+                    for (int b = 1; b <= n; b++) s.push_back(base_at(cur, b));
+                    cur = st[i]; hit = true; break;
+                }
+        if (!hit) { cur = st[i]; s.push_back(base_at(cur, 0)); }
+    }
+    for (int b = 1; b <= 4; b++) s.push_back(base_at(cur, b));
+    return s;
+}
+
+int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, double mmin, double mmax,
+                   std::vector<std::string>* out) {
+    out->clear();
+    const int E = a->E;
+    // host mirrors of ref_align / ref_index / refstart / refend
+    PS_TRY(a->refs_to_host(rt));
+    std::vector<double> h_ri(std::max<int64_t>(a->ntot, 1));
+    std::vector<JobOut> info(E);
+    PS_HIP(hipMemcpyAsync(h_ri.data(), a->d_ri, a->ntot * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipMemcpyAsync(info.data(), a->d_out, E * sizeof(JobOut), hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    // first level whose ref_index equals an integer position (std::find in getrefstates, cpp/EventData.h:192)
+    std::vector<std::map<int, int>> first(E);
+    int maxref = 0;
+    for (int e = 0; e < E; e++) {
+        if (!info[e].has_index) continue;  // empty ref_index: getrefstates finds nothing
+        const double* ri = h_ri.data() + a->off[e];
+        for (int t = 0; t < a->n[e]; t++) {
+            const double v = ri[t];
+            if (v == std::floor(v) && std::fabs(v) < 2e9) {
+                const int iv = (int)v;
+                if (!first[e].count(iv)) first[e][iv] = t;
+                maxref = std::max(maxref, iv);
+            }
+        }
+    }
+    auto rstart = [&](int e) { return info[e].has_index ? info[e].refstart : -1; };
+    auto rend = [&](int e) { return info[e].has_index ? info[e].refend : -1; };
+    int refind = rstart(0);
+    for (int e = 0; e < E; e++) refind = std::min(refind, rstart(e));
+    std::vector<double> obsin;
+    int T = 0;
+    while (true) {
+        int nl = 0, nal = 0;
+        const size_t at = obsin.size();
+        obsin.resize(at + (size_t)E * 4, 0.0);
+        for (int e = 0; e < E; e++) {
+            auto it = first[e].find(refind);
+            if (it == first[e].end()) continue;
+            const double* ra = a->h_ra.data() + a->off[e];
+            const double* mean = a->h_mean.data() + a->off[e];
+            const double* stdv = a->h_stdv.data() + a->off[e];
+            int t = it->second, cnt = 1;
+            double lvl = mean[t], sd = stdv[t];
+            // getrefstates keeps following levels while ref_align <= refind, using those > 0 (cpp/EventData.h:197-201)
+            double lsum = 0, ssum = 0;
+            lsum += mean[t]; ssum += stdv[t];
+            for (t++; t < a->n[e] && ra[t] <= refind; t++)
+                if (ra[t] > 0) { lsum += mean[t]; ssum += stdv[t]; cnt++; }
+            lvl = lsum / cnt; sd = ssum / cnt;
+            nl++;
+            double* o = obsin.data() + at + (size_t)e * 4;
+            o[0] = lvl; o[1] = sd; o[2] = std::log(sd); o[3] = 1.0;
+        }
+        for (int e = 0; e < E; e++) if (refind >= rstart(e) && refind <= rend(e)) nal++;
+        if (nl <= nal * 0.2) {
+            obsin.resize(at);
+            if (nal == 0) break;
+            refind++;
+            continue;
+        }
+        T++;
+        refind++;
+    }
+    if (T == 0) return PS_OK;
+    // uniform deviates in the reference's call order: for each kept path, one per back-step (cpp/Viterbi.cpp:108)
+    std::vector<double> rnd((size_t)nkeep * T);
+    for (size_t k = 0; k < rnd.size(); k++) rnd[k] = rand() / (double(RAND_MAX) + 1);
+    std::vector<std::vector<int>> paths;
+    PS_TRY(viterbi_device(rt, E, T, obsin.data(), a->d_model, nkeep, skip, stay, mmin, mmax, rnd.data(), &paths));
+    for (auto& p : paths) out->push_back(path_to_bases(p));
+    return PS_OK;
+}
+
+}  // namespace ps

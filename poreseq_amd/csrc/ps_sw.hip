@@ -1,7 +1,244 @@
-// placeholder until the Smith-Waterman kernels land
+// ps_sw.hip — full-matrix Smith-Waterman (swfull, cpp/swlib.cpp:211-340) on gfx950.
+//
+// Integer DP, +5 / -4 / -8, bit-exact with the reference including its tie rules
+// (left, then up with strict >, then diagonal with >=; first strict maximum in column-major
+// order starts the traceback; traceback stops at the first score <= 0).
+//
+// Tiling: 64 rows (one per lane) x TC columns per wave.  Lanes run systolically (lane l is l
+// columns behind lane 0); the value above comes from the neighbour lane by DPP, the tile's top
+// boundary row and left boundary column come from small global arrays written by the tiles
+// above / to the left, which finished on the previous tile anti-diagonal (one launch per tile
+// anti-diagonal, all sequence pairs of a batch in the same launch).
+// Step codes are stored per tile in the order they are produced ([t][lane], 64-byte coalesced
+// stores); the traceback pulls one whole tile into LDS and walks it there.
 #include "ps_internal.h"
+
 namespace ps {
-int sw_device(Runtime*, const std::string&, const std::string&, int*, double*, std::vector<int>*, std::vector<int>*) {
-    return fail(PS_ERR_UNSUPPORTED, "swfull: not built yet");
+
+constexpr int TC = 256;
+constexpr int TSTEPS = TC + 63;
+
+struct SwPair {
+    int n1, n2, ntr, ntc;
+    int64_t s1_off, s2_off;      // into the character pool
+    int64_t steps_off;           // into the step pool: ntr*ntc tiles of TSTEPS*64 bytes
+    int64_t hrow_off;            // 3 * (n2 + 1) ints
+    int64_t hcol_off;            // n1 + 1 ints
+    int64_t tile_off;            // ntr*ntc int4 {score, i, j, 0}
+    int64_t out_off;             // 2 * (n1 + n2 + 2) ints: index pairs in walk order
+    int64_t res_off;             // 8 ints: score, bi, bj, npairs, nmatch
+};
+
+__device__ __forceinline__ int shr1_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 }
+
+__global__ __launch_bounds__(64) void k_sw_tiles(const SwPair* pairs, const char* chars, unsigned char* steps,
+                                                 int* hrow, int* hcol, int4* tiles, int d) {
+    const SwPair& p = pairs[blockIdx.y];
+    const int rmin = max(0, d - (p.ntc - 1)), rmax = min(p.ntr - 1, d);
+    const int r = rmin + blockIdx.x;
+    if (r > rmax) return;
+    const int c = d - r, l = threadIdx.x;
+    const int i0 = r * 64, j0 = c * TC;
+    const int i = i0 + 1 + l;
+    const bool rowok = i <= p.n1;
+    const char* s1 = chars + p.s1_off;
+    const char* s2 = chars + p.s2_off;
+    int* hr_prev = hrow + p.hrow_off + (int64_t)((r + 2) % 3) * (p.n2 + 1);
+    int* hr_cur = hrow + p.hrow_off + (int64_t)(r % 3) * (p.n2 + 1);
+    int* hc = hcol + p.hcol_off;
+    __shared__ int s_top[TC + 1];
+    __shared__ int s_bot[TC];
+    __shared__ char s_c2[TC];
+    for (int k = l; k <= TC; k += 64) { const int j = j0 + k; s_top[k] = (r > 0 && j <= p.n2) ? hr_prev[j] : 0; }
+    for (int k = l; k < TC; k += 64) { const int j = j0 + 1 + k; s_c2[k] = j <= p.n2 ? s2[j - 1] : 0; s_bot[k] = 0; }
+    __syncthreads();
+    const char c1 = rowok ? s1[i - 1] : 1;
+    int left = (c > 0 && rowok) ? hc[i] : 0;       // H(i, j0)
+    int h = left;                                  // running H(i, j) of this lane
+    int prevup = shr1_i(left);                     // H(i-1, j0)
+    if (l == 0) prevup = s_top[0];
+    int best = 0, bestj = 0;
+    unsigned char* st = steps + p.steps_off + (int64_t)(r * p.ntc + c) * TSTEPS * 64;
+    for (int t = 0; t < TSTEPS; t++) {
+        const int jj = t - l;
+        int up = shr1_i(h);
+        if (l == 0) up = s_top[min(t + 1, TC)];
+        const int diag = prevup;
+        prevup = up;
+        unsigned char code = 0;
+        if (jj >= 0 && jj < TC && rowok && j0 + 1 + jj <= p.n2) {
+            int score = 0, step = 0;
+            int s = h - 8;                       // from the left: H(i, j-1)
+            if (s > score) { score = s; step = 1; }
+            s = up - 8;                          // from above: H(i-1, j)
+            if (s > score) { score = s; step = 2; }
+            const bool eq = c1 == s_c2[jj];
+            s = diag + (eq ? 5 : -4);
+            if (s >= score) { score = s; step = 3; }
+            h = score;
+            code = (unsigned char)(step | (score > 0 ? 4 : 0) | (eq ? 8 : 0));
+            if (score > best) { best = score; bestj = j0 + 1 + jj; }
+            if (l == 63) s_bot[jj] = score;
+        }
+        st[t * 64 + l] = code;
+    }
+    if (rowok) hc[i] = h;
+    // tile maximum: largest score, then smallest column, then smallest row (column-major first hit)
+    int bi = i, bj = best > 0 ? bestj : 0x7fffffff, bs = best;
+    for (int off = 32; off; off >>= 1) {
+        const int os = __shfl_xor(bs, off), oj = __shfl_xor(bj, off), oi = __shfl_xor(bi, off);
+        if (os > bs || (os == bs && (oj < bj || (oj == bj && oi < bi)))) { bs = os; bj = oj; bi = oi; }
+    }
+    if (l == 0) tiles[p.tile_off + r * p.ntc + c] = make_int4(bs, bi, bj, 0);
+    __syncthreads();
+    if (i0 + 64 <= p.n1)
+        for (int k = l; k < TC; k += 64) { const int j = j0 + 1 + k; if (j <= p.n2) hr_cur[j] = s_bot[k]; }
+    if (l == 0 && c == 0) hr_cur[0] = 0;
 }
+
+__global__ __launch_bounds__(64) void k_sw_best(const SwPair* pairs, const int4* tiles, int* res) {
+    const SwPair& p = pairs[blockIdx.x];
+    const int l = threadIdx.x, nt = p.ntr * p.ntc;
+    int bs = 0, bi = 0, bj = 0x7fffffff;
+    for (int k = l; k < nt; k += 64) {
+        const int4 v = tiles[p.tile_off + k];
+        if (v.x > bs || (v.x == bs && v.x > 0 && (v.z < bj || (v.z == bj && v.y < bi)))) { bs = v.x; bi = v.y; bj = v.z; }
+    }
+    for (int off = 32; off; off >>= 1) {
+        const int os = __shfl_xor(bs, off), oj = __shfl_xor(bj, off), oi = __shfl_xor(bi, off);
+        if (os > bs || (os == bs && os > 0 && (oj < bj || (oj == bj && oi < bi)))) { bs = os; bj = oj; bi = oi; }
+    }
+    if (l == 0) {
+        int* o = res + p.res_off;
+        o[0] = bs; o[1] = bs > 0 ? bi : 0; o[2] = bs > 0 ? bj : 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const unsigned char* steps, int* out, int* res) {
+    const SwPair& p = pairs[blockIdx.x];
+    const int l = threadIdx.x;
+    __shared__ unsigned char s_t[TSTEPS * 64];
+    int* o = res + p.res_off;
+    int i = o[1], j = o[2];
+    int np = 0, nm = 0;
+    int* oi = out + p.out_off;
+    int* oj = oi + (p.n1 + p.n2 + 2);
+    bool done = !(i > 0 && j > 0);
+    while (!done) {
+        const int r = (i - 1) / 64, c = (j - 1) / TC;
+        const int i0 = r * 64, j0 = c * TC;
+        const uint4* src = (const uint4*)(steps + p.steps_off + (int64_t)(r * p.ntc + c) * TSTEPS * 64);
+        uint4* dst = (uint4*)s_t;
+        for (int k = l; k < TSTEPS * 4; k += 64) dst[k] = src[k];
+        __syncthreads();
+        if (l == 0) {
+            while (true) {
+                if (!(i > 0 && j > 0)) { done = true; break; }
+                const int ll = i - i0 - 1, jj = j - j0 - 1;
+                if (ll < 0 || jj < 0) break;  // left this tile
+                const unsigned code = s_t[(jj + ll) * 64 + ll];
+                if (!(code & 4)) { done = true; break; }   // score <= 0
+                const unsigned stp = code & 3;
+                if (stp == 1) { oi[np] = 0; oj[np] = j; np++; j--; }
+                else if (stp == 2) { oi[np] = i; oj[np] = 0; np++; i--; }
+                else if (stp == 3) { oi[np] = i; oj[np] = j; np++; if (code & 8) nm++; i--; j--; }
+                else { done = true; break; }
+            }
+        }
+        i = __shfl(i, 0); j = __shfl(j, 0); np = __shfl(np, 0); nm = __shfl(nm, 0);
+        done = __shfl((int)done, 0) != 0;
+        __syncthreads();
+    }
+    if (l == 0) { o[3] = np; o[4] = nm; }
+}
+
+// -------------------------------------------------------------------------------------------------
+struct SwResult { int score = 0; double accuracy = 0; std::vector<int> a, b; };
+
+int sw_batch(Runtime* rt, const std::vector<std::pair<const std::string*, const std::string*>>& in, std::vector<SwResult>* out) {
+    const int np = (int)in.size();
+    out->assign(np, SwResult());
+    if (!np) return PS_OK;
+    std::vector<SwPair> pairs(np);
+    std::string pool;
+    int64_t steps_tot = 0, hrow_tot = 0, hcol_tot = 0, tile_tot = 0, out_tot = 0;
+    int maxdiag = 0, maxtiles = 0;
+    for (int k = 0; k < np; k++) {
+        SwPair& p = pairs[k];
+        p.n1 = (int)in[k].first->size(); p.n2 = (int)in[k].second->size();
+        p.ntr = std::max(1, (p.n1 + 63) / 64); p.ntc = std::max(1, (p.n2 + TC - 1) / TC);
+        p.s1_off = (int64_t)pool.size(); pool += *in[k].first;
+        p.s2_off = (int64_t)pool.size(); pool += *in[k].second;
+        p.steps_off = steps_tot; steps_tot += (int64_t)p.ntr * p.ntc * TSTEPS * 64;
+        p.hrow_off = hrow_tot; hrow_tot += 3 * ((int64_t)p.n2 + 1);
+        p.hcol_off = hcol_tot; hcol_tot += (int64_t)p.n1 + 1;
+        p.tile_off = tile_tot; tile_tot += (int64_t)p.ntr * p.ntc;
+        p.out_off = out_tot; out_tot += 2 * ((int64_t)p.n1 + p.n2 + 2);
+        p.res_off = (int64_t)k * 8;
+        maxdiag = std::max(maxdiag, p.ntr + p.ntc - 1);
+        maxtiles = std::max(maxtiles, std::min(p.ntr, p.ntc));
+    }
+    pool.push_back(0);
+    PS_TRY(rt->buf("sw_pairs").ensure(np * sizeof(SwPair)));
+    PS_TRY(rt->buf("sw_chars").ensure(pool.size()));
+    PS_TRY(rt->buf("sw_steps").ensure(steps_tot));
+    PS_TRY(rt->buf("sw_hrow").ensure(hrow_tot * sizeof(int)));
+    PS_TRY(rt->buf("sw_hcol").ensure(hcol_tot * sizeof(int)));
+    PS_TRY(rt->buf("sw_tiles").ensure(tile_tot * sizeof(int4)));
+    PS_TRY(rt->buf("sw_out").ensure(out_tot * sizeof(int)));
+    PS_TRY(rt->buf("sw_res").ensure((size_t)np * 8 * sizeof(int)));
+    SwPair* d_pairs = rt->buf("sw_pairs").as<SwPair>();
+    char* d_chars = rt->buf("sw_chars").as<char>();
+    unsigned char* d_steps = rt->buf("sw_steps").as<unsigned char>();
+    int* d_hrow = rt->buf("sw_hrow").as<int>();
+    int* d_hcol = rt->buf("sw_hcol").as<int>();
+    int4* d_tiles = rt->buf("sw_tiles").as<int4>();
+    int* d_out = rt->buf("sw_out").as<int>();
+    int* d_res = rt->buf("sw_res").as<int>();
+    PS_HIP(hipMemcpyAsync(d_pairs, pairs.data(), np * sizeof(SwPair), hipMemcpyHostToDevice, rt->stream));
+    PS_HIP(hipMemcpyAsync(d_chars, pool.data(), pool.size(), hipMemcpyHostToDevice, rt->stream));
+    PS_HIP(hipMemsetAsync(d_res, 0, (size_t)np * 8 * sizeof(int), rt->stream));
+    prof_begin(rt);
+    for (int d = 0; d < maxdiag; d++) {
+        hipLaunchKernelGGL(k_sw_tiles, dim3(maxtiles, np), dim3(64), 0, rt->stream, d_pairs, d_chars, d_steps, d_hrow, d_hcol, d_tiles, d);
+    }
+    PS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_sw_best, dim3(np), dim3(64), 0, rt->stream, d_pairs, d_tiles, d_res);
+    hipLaunchKernelGGL(k_sw_trace, dim3(np), dim3(64), 0, rt->stream, d_pairs, d_steps, d_out, d_res);
+    PS_HIP(hipGetLastError());
+    double cells = 0;
+    for (auto& p : pairs) cells += (double)p.n1 * p.n2;
+    prof_end(rt, "sw", cells * 5.0);  // 4-byte score + 1-byte step per cell (the reference's footprint)
+    std::vector<int> res((size_t)np * 8);
+    PS_HIP(hipMemcpyAsync(res.data(), d_res, res.size() * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    std::vector<int> tmp;
+    for (int k = 0; k < np; k++) {
+        const int n = res[k * 8 + 3], nm = res[k * 8 + 4];
+        SwResult& r = (*out)[k];
+        r.score = res[k * 8 + 0];
+        r.a.resize(n); r.b.resize(n);
+        if (n) {
+            PS_HIP(hipMemcpyAsync(r.a.data(), d_out + pairs[k].out_off, n * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
+            PS_HIP(hipMemcpyAsync(r.b.data(), d_out + pairs[k].out_off + (pairs[k].n1 + pairs[k].n2 + 2), n * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
+        }
+        r.accuracy = 100.0 * nm / (double)n;  // NaN for an empty alignment, as the reference computes it
+    }
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    for (auto& r : *out) { std::reverse(r.a.begin(), r.a.end()); std::reverse(r.b.begin(), r.b.end()); }
+    return PS_OK;
+}
+
+int sw_device(Runtime* rt, const std::string& s1, const std::string& s2, int* score, double* accuracy,
+              std::vector<int>* inds1, std::vector<int>* inds2) {
+    std::vector<std::pair<const std::string*, const std::string*>> in(1, {&s1, &s2});
+    std::vector<SwResult> out;
+    PS_TRY(sw_batch(rt, in, &out));
+    *score = out[0].score; *accuracy = out[0].accuracy;
+    inds1->swap(out[0].a); inds2->swap(out[0].b);
+    return PS_OK;
+}
+
+}  // namespace ps

@@ -1,0 +1,217 @@
+"""GPU parity tests: the HIP path (through the C ABI, via poreseqcpp.PSAlign) against the oracle on
+the same seeded inputs and against the reference's golden vectors.  Integer / index / max-plus work
+is required bit-exact; the only tolerance is on ViterbiMutate's forward probabilities, which feed
+nothing but the stochastic back-traces (checked through the resulting sequences)."""
+import copy
+
+import numpy as np
+import pytest
+
+import backends as B
+import golden_util as G
+from poreseq_amd import _capi, synth
+from poreseq_amd.poreseqcpp import PSAlign, swalign, seqtostates
+from poreseq_amd.util import DEFAULT_PARAMS, MutationInfo
+
+pytestmark = pytest.mark.gpu
+P0 = dict(DEFAULT_PARAMS, verbose=0)
+SCORE_CASES = ["score_L300_E5", "score_L240_E4_narrow"]
+
+
+def scores(lst):
+    return np.array([s.score for s in lst])
+
+
+def test_backend_is_the_hip_library():
+    assert _capi.load_hip().backend_name() == "hip-gfx950"
+
+
+@pytest.mark.parametrize("name", SCORE_CASES)
+def test_golden_score_events_points_mutations(name):
+    z = G.load(name)
+    assert np.array_equal(np.array(G.make(PSAlign, z).ScoreEvents()), z["ScoreEvents"])
+    got = G.make(PSAlign, z).ScorePoints()
+    assert [g.start for g in got] == z["ScorePoints_start"].tolist()
+    assert np.array_equal(scores(got), z["ScorePoints_score"])
+    got = G.make(PSAlign, z).ScoreMutations(G.muts_of(z))
+    assert np.array_equal(scores(got), z["ScoreMutations_score"])
+
+
+def test_golden_consensus_schedule():
+    z = G.load("consensus_L400_E6")
+    B.reset_rand()
+    pa = G.make(PSAlign, z)
+    for call, nb, seq in zip(z["calls"], z["nbases"], z["sequences"]):
+        call = str(call)
+        got = pa.Mutate(reps=4) if call == "Mutate:self" else pa.Mutate(seqs="viterbi") if call == "Mutate:viterbi" else pa.Refine()
+        assert got == int(nb), call
+        assert pa.sequence == str(seq), call
+    for e, ev in enumerate(pa.events):
+        assert np.array_equal(ev.ref_align, z["final_ev%d_ref_align" % e])
+        assert np.array_equal(ev.ref_like, z["final_ev%d_ref_like" % e])
+
+
+def test_golden_sw_states():
+    z = G.load("sw_states")
+    acc, pairs = swalign(str(z["s1"]), str(z["s2"]))
+    assert acc == float(z["accuracy"])
+    assert np.array_equal(np.array(pairs, dtype=np.int32), z["pairs"])
+    assert seqtostates(str(z["odd"])) == z["odd_states"].tolist()
+
+
+@pytest.mark.parametrize("L,E,seed,par", [
+    (300, 5, 11, P0),
+    (700, 6, 12, P0),
+    (260, 4, 13, dict(P0, realign_width=33.0, scoring_width=9.0, point_width=4.0)),
+    (1000, 5, 1001, P0),   # BASELINE config #1 shape
+])
+def test_dp_matrices_bit_exact(L, E, seed, par):
+    """K1/K2 parity: full forward / backward main + stay matrices and step codes vs the oracle."""
+    draft, events, truth = synth.make_region(L, E, seed, B.oracle_swalign, par)
+    hip, orc = _capi.load_hip(), B.oracle_api()
+    for d in (0, 1):
+        for e in (0, E - 1):
+            outs = []
+            for api in (orc, hip):
+                h = api.align_create(draft, copy.deepcopy(events), par)
+                outs.append(api.debug_fill(h, e, d, events[e].mean.size, len(draft) - 4))
+                api.align_destroy(h)
+            for x, y in zip(*outs):
+                assert np.array_equal(x, y, equal_nan=True), (d, e)
+
+
+@pytest.mark.parametrize("L,E,seed,par", [
+    (300, 5, 21, P0),
+    (500, 10, 22, P0),
+    (260, 4, 23, dict(P0, realign_width=33.0, scoring_width=9.0, point_width=4.0)),
+])
+def test_api_parity_with_oracle(L, E, seed, par):
+    draft, events, truth = synth.make_region(L, E, seed, B.oracle_swalign, par)
+    mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(events), par)
+    assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents()
+    a, b = mk(PSAlign).ScorePoints(), mk(B.OraclePSAlign).ScorePoints()
+    assert np.array_equal(scores(a), scores(b))
+    rng = np.random.default_rng(seed)
+    muts = synth.random_point_mutations(rng, draft, 60)
+    for st, o, m in [(10, draft[10:13], "ACGTA"), (40, draft[40:52], ""), (60, "", "ACGTACGTACGTACGTACGTAC"),
+                     (L - 3, draft[L - 3:L - 2], "G"), (len(draft), "", "A"), (len(draft) + 3, "", "A"), (0, "", "TT"),
+                     (100, draft[100:101], "T" * 70), (5, draft[5:9], "G" * 30)]:
+        mi = MutationInfo(); mi.start, mi.orig, mi.mut = st, o, m
+        muts.append(mi)
+    a, b = mk(PSAlign).ScoreMutations(muts), mk(B.OraclePSAlign).ScoreMutations(muts)
+    assert np.array_equal(scores(a), scores(b))
+    # in-place calls: Refine, Mutate(list), ApplyMuts
+    x, y = mk(PSAlign), mk(B.OraclePSAlign)
+    assert x.Refine() == y.Refine() and x.sequence == y.sequence
+    for u, v in zip(x.events, y.events):
+        assert np.array_equal(u.ref_align, v.ref_align) and np.array_equal(u.ref_like, v.ref_like)
+    x, y = mk(PSAlign), mk(B.OraclePSAlign)
+    seeds = [ev.sequence for ev in events[:3]]
+    assert x.Mutate(seqs=seeds, reps=3) == y.Mutate(seqs=seeds, reps=3) and x.sequence == y.sequence
+    x, y = mk(PSAlign), mk(B.OraclePSAlign)
+    sc = mk(B.OraclePSAlign).ScorePoints()
+    x.ApplyMuts(sc); y.ApplyMuts(sc)
+    assert x.sequence == y.sequence
+
+
+def test_full_consensus_schedule_matches_oracle():
+    """Row H: Mutate('self') then {Mutate('viterbi'), Refine()} until no change — identical edits."""
+    draft, events, truth = synth.make_region(600, 10, 31, B.oracle_swalign, P0)
+    res = []
+    for cls in (PSAlign, B.OraclePSAlign):
+        B.reset_rand()
+        pa = B.make_pa(cls, draft, copy.deepcopy(events), P0)
+        log = [pa.Mutate(reps=4), pa.sequence]
+        for _ in range(4):
+            log += [pa.Mutate(seqs="viterbi"), pa.sequence]
+            nb = pa.Refine()
+            log += [nb, pa.sequence]
+            if nb == 0:
+                break
+        res.append(log)
+    assert res[0] == res[1]
+
+
+def test_viterbi_seeds_match_oracle():
+    draft, events, truth = synth.make_region(400, 8, 41, B.oracle_swalign, P0)
+    for nkeep in (0, 16):
+        out = []
+        for api in (_capi.load_hip(), B.oracle_api()):
+            B.reset_rand()
+            h = api.align_create(draft, copy.deepcopy(events), P0)
+            out.append(api.viterbi_mutate(h, nkeep, 0.05, 0.01, 0.33, 0.75, 0))
+            api.align_destroy(h)
+        assert out[0] == out[1], nkeep
+
+
+def test_sw_parity_and_properties():
+    rng = np.random.default_rng(5)
+    for n1, n2 in [(1, 1), (5, 300), (300, 5), (64, 256), (65, 257), (700, 900), (2100, 1900)]:
+        s1 = synth.random_sequence(rng, n1)
+        s2 = synth.corrupt(rng, s1, 0.05, 0.05, 0.05) if n2 >= n1 // 2 and n1 > 10 else synth.random_sequence(rng, n2)
+        a, b = swalign(s1, s2), B.oracle_swalign(s1, s2)
+        assert a[1] == b[1]
+        assert (a[0] == b[0]) or (np.isnan(a[0]) and np.isnan(b[0]))
+    s = synth.random_sequence(rng, 3000)          # identity: full-length diagonal, 100 %
+    acc, pairs = swalign(s, s)
+    assert acc == 100.0 and pairs == [(i, i) for i in range(1, 3001)]
+    assert swalign("", "ACGT")[1] == []
+
+
+def test_edge_cases_match_oracle():
+    draft, events, truth = synth.make_region(150, 4, 51, B.oracle_swalign, P0, draft_error=0.0)
+    ev = copy.deepcopy(events)
+    ev[1].ref_align[:] = 0                       # inert event
+    ev[2].ref_align[5:] = 0                      # barely aligned event
+    mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(ev), P0)
+    assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents()
+    assert np.array_equal(scores(mk(PSAlign).ScorePoints()), scores(mk(B.OraclePSAlign).ScorePoints()))
+    odd = draft[:40] + "-" + draft[41:90] + "N" + draft[91:]   # invalid states
+    mk2 = lambda cls: B.make_pa(cls, odd, copy.deepcopy(events), P0)
+    assert mk2(PSAlign).ScoreEvents() == mk2(B.OraclePSAlign).ScoreEvents()
+    assert np.array_equal(scores(mk2(PSAlign).ScorePoints()), scores(mk2(B.OraclePSAlign).ScorePoints()))
+    assert B.make_pa(PSAlign, "ACGTACGTAC", [], P0).ScoreEvents() == []
+    assert len(B.make_pa(PSAlign, "ACGTACGTAC", [], P0).ScorePoints()) == 48
+    with pytest.raises(_capi.PoreseqError):
+        B.make_pa(PSAlign, draft, copy.deepcopy(events), dict(P0, realign_width=600.0)).ScoreEvents()
+    m = MutationInfo(); m.start = -2; m.mut = "A"
+    with pytest.raises(_capi.PoreseqError):
+        B.make_pa(PSAlign, draft, copy.deepcopy(events), P0).ScoreMutations([m])
+
+
+def test_realign_to_and_copy():
+    draft, events, truth = synth.make_region(300, 4, 61, B.oracle_swalign, P0)
+    x, y = B.make_pa(PSAlign, draft, copy.deepcopy(events), P0), B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), P0)
+    xc = x.Copy()
+    x.RealignTo(truth); y.RealignTo(truth)
+    assert x.sequence == truth and xc.sequence == draft
+    assert x.ScoreEvents() == y.ScoreEvents()
+    assert np.array_equal(x.Coverage(), y.Coverage())
+
+
+def test_large_properties_config2_shape():
+    """BASELINE config #2 size (10 kb, 10 events): size-independent properties instead of the oracle."""
+    draft, events, truth = synth.make_region(10000, 10, 1002, swalign, P0, draft_error=0.0)
+    pa = B.make_pa(PSAlign, draft, copy.deepcopy(events), P0)
+    s1 = pa.ScoreEvents()
+    assert s1 == pa.ScoreEvents()                      # idempotent / deterministic
+    assert all(2.0 * len(draft) < s < 3.0 * len(draft) for s in s1)   # ~2.2-2.4 per base
+    # additivity over events: scoring a subset of events gives the same per-event scores
+    sub = B.make_pa(PSAlign, draft, copy.deepcopy(events[3:6]), P0).ScoreEvents()
+    assert sub == s1[3:6]
+    # planted errors are found: corrupt 3 bases, the reverting edits get the top positive scores
+    bad = list(draft)
+    for p in (2000, 5000, 8000):
+        bad[p] = "ACGT"[("ACGT".index(bad[p]) + 1) % 4]
+    bad = "".join(bad)
+    pb = B.make_pa(PSAlign, bad, copy.deepcopy(events), P0)
+    muts = []
+    for p in (2000, 5000, 8000):
+        m = MutationInfo(); m.start, m.orig, m.mut = p, bad[p], draft[p]
+        muts.append(m)
+    m = MutationInfo(); m.start, m.orig, m.mut = 3000, bad[3000], "ACGT"[("ACGT".index(bad[3000]) + 1) % 4]
+    muts.append(m)
+    sc = scores(pb.ScoreMutations(muts))
+    assert (sc[:3] > 20).all() and sc[3] < 0
+    nb = pb.Refine()
+    assert nb >= 3 and draft[300:-300] in pb.sequence      # the planted errors are repaired (ends may legitimately move)

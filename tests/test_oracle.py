@@ -1,0 +1,161 @@
+"""CPU tests: the oracle against the reference's golden vectors (and the live reference build
+when oracle/_ref is present), the C ABI exports of the product library, host-side helpers."""
+import copy
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import backends as B
+import golden_util as G
+from poreseq_amd import _capi, synth
+from poreseq_amd.util import DEFAULT_PARAMS, MutationInfo, MutationScore, RegionInfo, LoadParams, SaveParams
+
+SCORE_CASES = ["score_L300_E5", "score_L240_E4_narrow"]
+
+
+@pytest.mark.parametrize("name", SCORE_CASES)
+def test_oracle_score_events_golden(name):
+    z = G.load(name)
+    got = G.make(B.OraclePSAlign, z).ScoreEvents()
+    assert np.array_equal(np.array(got), z["ScoreEvents"])  # bit-exact
+
+
+@pytest.mark.parametrize("name", SCORE_CASES)
+def test_oracle_score_points_golden(name):
+    z = G.load(name)
+    got = G.make(B.OraclePSAlign, z).ScorePoints()
+    assert [g.start for g in got] == z["ScorePoints_start"].tolist()
+    assert [g.orig for g in got] == [str(x) for x in z["ScorePoints_orig"]]
+    assert [g.mut for g in got] == [str(x) for x in z["ScorePoints_mut"]]
+    assert np.array_equal(np.array([g.score for g in got]), z["ScorePoints_score"])
+
+
+@pytest.mark.parametrize("name", SCORE_CASES)
+def test_oracle_score_mutations_golden(name):
+    z = G.load(name)
+    got = G.make(B.OraclePSAlign, z).ScoreMutations(G.muts_of(z))
+    assert np.array_equal(np.array([g.score for g in got]), z["ScoreMutations_score"])
+    assert [g.start for g in got] == z["ScoreMutations_start"].tolist()
+
+
+def test_oracle_consensus_schedule_golden():
+    """Mutate.py:70-85 schedule: per-call nbases, sequence after every call, final refs."""
+    z = G.load("consensus_L400_E6")
+    B.reset_rand()
+    pa = G.make(B.OraclePSAlign, z)
+    for call, nb, seq in zip(z["calls"], z["nbases"], z["sequences"]):
+        call = str(call)
+        if call == "Mutate:self":
+            got = pa.Mutate(reps=4)
+        elif call == "Mutate:viterbi":
+            got = pa.Mutate(seqs="viterbi")
+        else:
+            got = pa.Refine()
+        assert got == int(nb), call
+        assert pa.sequence == str(seq), call
+    for e, ev in enumerate(pa.events):
+        assert np.array_equal(ev.ref_align, z["final_ev%d_ref_align" % e])
+        assert np.array_equal(ev.ref_like, z["final_ev%d_ref_like" % e])
+
+
+def test_oracle_sw_and_states_golden():
+    z = G.load("sw_states")
+    acc, pairs = B.oracle_swalign(str(z["s1"]), str(z["s2"]))
+    assert acc == float(z["accuracy"])
+    assert np.array_equal(np.array(pairs, dtype=np.int32), z["pairs"])
+    assert B.seqtostates(str(z["odd"]), B.oracle_api) == z["odd_states"].tolist()
+    assert B.seqtostates(str(z["s1"]), B.oracle_api) == z["s1_states"].tolist()
+    assert B.seqtostates("ACG", B.oracle_api) == []
+
+
+@pytest.mark.skipif(not B.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_matches_live_reference_full_api():
+    P = dict(DEFAULT_PARAMS, verbose=0)
+    draft, events, truth = synth.make_region(350, 5, 4242, B.ref_swalign, P)
+    logs = {}
+    for cls in (B.RefPSAlign, B.OraclePSAlign):
+        B.reset_rand()
+        pa = B.make_pa(cls, draft, copy.deepcopy(events), P)
+        log = [pa.ScoreEvents(), [s.score for s in pa.ScorePoints()]]
+        log.append(pa.Mutate(reps=2)); log.append(pa.sequence)
+        log.append(pa.Mutate(seqs="viterbi", reps=2)); log.append(pa.sequence)
+        log.append(pa.Refine()); log.append(pa.sequence)
+        log.append([e.ref_align.tolist() for e in pa.events])
+        logs[cls.__name__] = log
+    assert logs["RefPSAlign"] == logs["OraclePSAlign"]
+    for d in (0, 1):
+        outs = []
+        for api in (B.ref_api(), B.oracle_api()):
+            h = api.align_create(draft, copy.deepcopy(events), P)
+            outs.append(api.debug_fill(h, 1, d, events[1].mean.size, len(draft) - 4))
+            api.align_destroy(h)
+        for x, y in zip(*outs):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_oracle_edge_cases():
+    P = dict(DEFAULT_PARAMS, verbose=0)
+    draft, events, truth = synth.make_region(120, 3, 7, B.oracle_swalign, P, draft_error=0.0)
+    # an event with no alignment at all is inert: scores 0, refs untouched (Alignment.cpp:51-59)
+    ev = copy.deepcopy(events)
+    ev[1].ref_align[:] = 0
+    pa = B.make_pa(B.OraclePSAlign, draft, ev, P)
+    s = pa.ScoreEvents()
+    assert s[1] == 0.0 and s[0] > 0
+    # no events, tiny sequence
+    pa0 = B.make_pa(B.OraclePSAlign, "ACGTACGTAC", [], P)
+    assert pa0.ScoreEvents() == []
+    assert len(pa0.ScorePoints()) == 8 * 6  # 1 deletion + 3 substitutions + 4 insertions per state
+    # edit past the end is skipped: score stays at the -1e-6 seed (MakeMutations.cpp:46-47, AlignUtil.h:86)
+    m = MutationInfo(); m.start = len(draft) + 5; m.mut = "A"
+    out = B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), P).ScoreMutations([m])
+    assert out[0].score == -1e-6
+
+
+def test_library_exports_every_declared_symbol():
+    """The shipped .so must load (no GPU needed) and export every entry point of include/poreseq_hip.h."""
+    import re
+    hdr = open(os.path.join(B.ROOT, "include", "poreseq_hip.h")).read()
+    declared = set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    lib = ctypes.CDLL(_capi.HIP_LIB)
+    for name in declared:
+        assert hasattr(lib, name), name
+    api = _capi.load_hip()
+    assert api.backend_name() == "hip-gfx950"
+
+
+def test_product_has_no_path_to_the_oracle():
+    pkg = os.path.join(B.ROOT, "poreseq_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "libps_oracle" not in txt and "oracle/" not in txt.replace("oracle/ ", ""), fn
+
+
+def test_util_types_and_params(tmp_path):
+    m = MutationInfo("12\tA\t.")
+    assert (m.start, m.orig, m.mut) == (12, "A", "") and str(m) == "12\tA\t."
+    assert MutationInfo("# comment").start == -1 and MutationInfo("1 2").start == -1
+    s = MutationScore(); s.start, s.orig, s.mut, s.score = 3, "", "GT", 1.5
+    assert str(s) == "3\t.\tGT\t1.5"
+    r = RegionInfo("chr1:100:200")
+    assert (r.name, r.start, r.end) == ("chr1", 100, 200)
+    assert RegionInfo("10:20").name is None and RegionInfo("abc").start is None
+    p = tmp_path / "p.conf"
+    SaveParams(str(p), {"a": 1.5, "b": 2.0})
+    assert LoadParams(str(p)) == {"a": 1.5, "b": 2.0}
+    assert LoadParams(None) == {}
+
+
+def test_event_mapaligns_and_setparams():
+    draft, events, truth = synth.make_region(100, 2, 3, B.oracle_swalign, dict(DEFAULT_PARAMS), draft_error=0.0)
+    ev = events[0]
+    before = ev.ref_align.copy()
+    pairs = np.array([(i, i + 2) for i in range(1, 200)])
+    ev.mapaligns(pairs)
+    assert np.array_equal(ev.ref_align[before > 0], before[before > 0] + 2)
+    assert events[0].model.prob_skip == DEFAULT_PARAMS["skip_t"] and events[1].model.prob_skip == DEFAULT_PARAMS["skip_c"]
