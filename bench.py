@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py — kb of consensus refined per second at 10x coverage (BASELINE.json metric).
+
+One "step" = the full `poreseq consensus` schedule (Mutate('self') then up to 4 x {Mutate('viterbi'),
+Refine()}, poreseq/Mutate.py:70-85) on ONE synthetic 10 kb region with 10 event streams
+(BASELINE.json configs[1]), through the drop-in PSAlign API and the C ABI, on one GPU.
+With N GPUs every rank refines its own region per step (regions are independent work-items;
+weak scaling) and the value is the whole-job rate:  N * region_kb * K / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--length L] [--events E]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0, with the `roofline` of the dominant kernel (HIP-event time on the
+library's own stream in a separate profiled pass) and the `cpu_baseline` (the reference's C++ when
+oracle/_ref is built, else the oracle restatement) timed on a bounded sample.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--length", type=int, default=10000)
+    ap.add_argument("--events", type=int, default=10)
+    ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    from poreseq_amd import dist as psdist
+    rank, local, world = psdist.init()
+    import torch
+    from poreseq_amd import _capi, synth
+    from poreseq_amd.consensus import consensus_region
+    from poreseq_amd.poreseqcpp import PSAlign, swalign
+    from poreseq_amd.util import DEFAULT_PARAMS
+
+    params = dict(DEFAULT_PARAMS, verbose=0)
+    api = _capi.load_hip()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+
+    def make(seed):
+        draft, events, truth = synth.make_region(args.length, args.events, seed, swalign, params)
+        return draft, events, truth
+
+    def run(region):
+        draft, events, truth = region
+        pa = PSAlign()
+        pa.sequence, pa.events, pa.params = draft, copy.deepcopy(events), dict(params)
+        seq, _ = consensus_region(pa, params)
+        return seq, truth
+
+    # synthetic inputs for every step of this rank, generated outside the timed region
+    nsteps = args.warmup + args.steps
+    regions = [make(1002 + 1000 * rank + s) for s in range(nsteps)]
+    for s in range(args.warmup):
+        run(regions[s])
+    psdist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    accs = []
+    for s in range(args.warmup, nsteps):
+        seq, truth = run(regions[s])
+        accs.append((seq, truth))
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    psdist.barrier()
+    dt = psdist.max_over_ranks(time.perf_counter() - t0)
+    kb = args.length / 1000.0
+    value = world * kb * args.steps / dt
+
+    out = {
+        "metric": "kb consensus refined/sec at 10x coverage", "value": value, "unit": "kb/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / max(args.steps, 1),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "poreseq consensus, %d kb region, %dx synthetic coverage (BASELINE configs[1]), full "
+                               "Mutate.py schedule per region, one region per GPU per step" % (args.length // 1000, args.events),
+                   "region_bases": args.length, "events": args.events, "parallelism": "regions x%d" % world},
+    }
+
+    if rank == 0:
+        # accuracy of the refined consensus (trimmed by end_trim) against the synthetic truth
+        a0 = swalign(regions[-1][0], regions[-1][2])[0]
+        a1 = swalign(accs[-1][0], accs[-1][1])[0]
+        out["accuracy"] = {"draft_percent": a0, "consensus_percent": a1}
+
+        # ---- roofline of the dominant kernel: separate profiled pass (HIP events around each launch) ----
+        api.prof_reset()
+        api.prof_enable(True)
+        run(regions[-1])
+        api.prof_enable(False)
+        prof = {k: api.prof_get(k) for k in ("fill", "score", "sw", "viterbi")}
+        dom = max(prof, key=lambda k: prof[k][0])
+        ms, launches, nbytes = prof[dom]
+        achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": {"fill": "k_recur", "score": "k_score", "sw": "k_sw_tiles",
+                                                      "viterbi": "k_vit_steps"}[dom],
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+                           "alg_bytes_per_launch": nbytes / max(launches, 1),
+                           "all_kernel_classes_ms": {k: v[0] for k, v in prof.items()}}
+
+        # ---- parity spot-check + CPU baseline (oracle / reference: checker and baseline only) ----
+        if world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import backends as B
+            use_ref = B.have_ref()
+            cls = B.RefPSAlign if use_ref else B.OraclePSAlign
+            cpu_sw = B.ref_swalign if use_ref else B.oracle_swalign
+            d, ev, tr = synth.make_region(400, 6, 77, cpu_sw, params)
+            g = B.make_pa(PSAlign, d, copy.deepcopy(ev), params).ScoreEvents()
+            c = B.make_pa(cls, d, copy.deepcopy(ev), params).ScoreEvents()
+            gp = B.make_pa(PSAlign, d, copy.deepcopy(ev), params).ScorePoints()
+            cp = B.make_pa(cls, d, copy.deepcopy(ev), params).ScorePoints()
+            rel = max([abs(x - y) / max(abs(y), 1e-300) for x, y in zip(g, c)] +
+                      [abs(x.score - y.score) / abs(y.score) for x, y in zip(gp, cp) if abs(y.score) > 1e-3])
+            out["logl_max_rel_err_vs_cpu"] = rel
+            if not args.no_cpu:
+                d, ev, tr = synth.make_region(args.cpu_length, args.events, 1002, cpu_sw, params)
+                pa = B.make_pa(cls, d, copy.deepcopy(ev), params)
+                B.reset_rand()
+                t = time.perf_counter()
+                consensus_region(pa, params)
+                ct = time.perf_counter() - t
+                out["cpu_baseline"] = {
+                    "value": (args.cpu_length / 1000.0) / ct, "unit": "kb/s", "cores": 1,
+                    "kind": "reference" if use_ref else "port",
+                    "sample": "full consensus schedule on one %d-base region, %d events, single thread (%.1f s); the "
+                              "reference is O(L^2) per region, so its 10 kb rate is ~5x lower per kb (BASELINE.md 2a)"
+                              % (args.cpu_length, args.events, ct),
+                    "host_cores_available": os.cpu_count()}
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

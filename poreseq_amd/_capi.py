@@ -65,6 +65,7 @@ SYMBOLS = {
                             c_i32p, C.c_int64, c_i64p]),
     "ps_seq_to_states": (C.c_int, [C.c_char_p, C.c_int64, c_i32p, c_i64p]),
     "ps_debug_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_dp, c_dp, c_u8p, c_u8p]),
+    "ps_prof_enable": (C.c_int, [C.c_int32]),
     "ps_prof_reset": (C.c_int, []),
     "ps_prof_get": (C.c_int, [C.c_char_p, c_dp, c_i64p, c_dp]),
 }
@@ -276,6 +277,9 @@ class CApi:
         self.check(self.lib.ps_debug_fill(h, ev, direction, _dp(main), _dp(stay),
                                           sm.ctypes.data_as(c_u8p), ss.ctypes.data_as(c_u8p)))
         return main, stay, sm, ss
+
+    def prof_enable(self, on):
+        self.check(self.lib.ps_prof_enable(1 if on else 0))
 
     def prof_reset(self):
         self.check(self.lib.ps_prof_reset())

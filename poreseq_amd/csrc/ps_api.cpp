@@ -186,10 +186,14 @@ int ps_debug_fill(ps_align* a, int32_t e, int32_t dir, double* main, double* sta
     return debug_fill(rt, &a->a, e, dir, main, stay, sm, ss);
 }
 
+int ps_prof_enable(int32_t on) {
+    NEED_RT();
+    rt->prof_on = on != 0;
+    return PS_OK;
+}
 int ps_prof_reset(void) {
     NEED_RT();
     rt->prof.clear();
-    rt->prof_on = true;
     return PS_OK;
 }
 int ps_prof_get(const char* name, double* ms, int64_t* n, double* bytes) {

@@ -1,0 +1,102 @@
+"""Multi-GPU execution: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on
+ROCm, "gloo" on CPU for tests).  The path shards by *region*: regions are independent work-items by
+construction (cmdline.py:182-195, split_fasta.py:50-133), so there is no data-path collective; the only
+exchange is the final gather of each region's consensus sequence and per-event log-likelihoods.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("PORESEQ_DEVICE", str(local))   # read by libporeseq_hip when it first touches the GPU
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def device():
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def shard(items, rank, world):
+    """Round-robin assignment of region work-items to ranks."""
+    return [(i, it) for i, it in enumerate(items) if i % world == rank]
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(x):
+    if not dist.is_initialized():
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_regions(local_results, n_regions, max_events):
+    """All ranks receive every region's (sequence, per-event scores).
+
+    local_results: list of (region_index, sequence str, scores float64[<= max_events]).
+    Payload: one uint8 tensor (sequences, padded) and one float64 tensor (scores) per rank, exchanged
+    with all_gather — RCCL over xGMI under the nccl backend; a few KB per region, latency-bound.
+    """
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    per = (n_regions + world - 1) // world
+    maxlen = max([len(s) for _, s, _ in local_results] + [0])
+    maxlen = int(max_over_ranks(maxlen))
+    dev = device()
+    seqs = torch.zeros((per, maxlen + 1), dtype=torch.uint8, device=dev)
+    meta = torch.full((per, 2), -1, dtype=torch.int64, device=dev)
+    scores = torch.zeros((per, max_events), dtype=torch.float64, device=dev)
+    for k, (idx, s, sc) in enumerate(local_results):
+        b = np.frombuffer(s.encode("ascii"), dtype=np.uint8)
+        seqs[k, :len(b)] = torch.from_numpy(b.copy()).to(dev)
+        meta[k, 0], meta[k, 1] = idx, len(b)
+        sc = np.asarray(sc, dtype=np.float64)
+        scores[k, :len(sc)] = torch.from_numpy(sc).to(dev)
+    if world > 1:
+        gs = [torch.empty_like(seqs) for _ in range(world)]
+        gm = [torch.empty_like(meta) for _ in range(world)]
+        gc = [torch.empty_like(scores) for _ in range(world)]
+        dist.all_gather(gs, seqs)
+        dist.all_gather(gm, meta)
+        dist.all_gather(gc, scores)
+    else:
+        gs, gm, gc = [seqs], [meta], [scores]
+    out = [None] * n_regions
+    for r in range(world):
+        m = gm[r].cpu().numpy()
+        s = gs[r].cpu().numpy()
+        c = gc[r].cpu().numpy()
+        for k in range(per):
+            idx, ln = int(m[k, 0]), int(m[k, 1])
+            if idx >= 0:
+                out[idx] = (s[k, :ln].tobytes().decode("ascii"), c[k].copy())
+    return out
+
+
+def run_regions(regions, process, max_events=64):
+    """Shard `regions` over the ranks, run process(region) -> (sequence, scores) locally, gather."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    local = []
+    for idx, reg in shard(regions, rank, world):
+        seq, sc = process(reg)
+        local.append((idx, seq, sc))
+    return gather_regions(local, len(regions), max_events)
