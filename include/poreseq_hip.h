@@ -128,7 +128,9 @@ int ps_seq_to_states(const char* seq, int64_t n, int32_t* states, int64_t* n_sta
  * Runs Alignment::update (cpp/Alignment.cpp:63-73) for one event on the current sequence
  * and returns the dense (n_levels+1) x (n_states+1) forward or backward main matrix with
  * out-of-band cells as NaN; direction 0 = forward (column index = ref position), 1 = backward
- * (column index k = -col, cpp/Alignment.cpp:284-285).  stay (may be NULL) gets the stay matrix. */
+ * (column index k = -col, cpp/Alignment.cpp:284-285).  stay (may be NULL) gets the stay matrix.
+ * Step codes are returned for the forward matrix only — the only ones the reference ever reads
+ * (backtrace, cpp/Alignment.cpp:516-624); for direction 1 they are zero. */
 int ps_debug_fill(ps_align* a, int32_t ev, int32_t direction, double* main, double* stay,
                   uint8_t* step_main, uint8_t* step_stay);
 

@@ -43,8 +43,9 @@ int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* sta
             const size_t to = (size_t)i * ld + c;
             main[to] = rec[at].x;
             if (stay) stay[to] = rec[at].y;
-            if (sm) sm[to] = (uint8_t)(flg[at] & 255);
-            if (ss) ss[to] = (uint8_t)(flg[at] >> 8);
+            // back-pointer codes exist for the forward matrix only (nothing reads the backward ones)
+            if (sm && dir == 0) sm[to] = (uint8_t)(flg[at] & 255);
+            if (ss && dir == 0) ss[to] = (uint8_t)(flg[at] >> 8);
         }
     }
     return PS_OK;

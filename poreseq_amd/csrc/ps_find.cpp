@@ -56,14 +56,14 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
         for (size_t q = 0; q < need.size(); q++) sstates[q] = states_of(seeds[need[q]]);
         // chunk the seeds so the DP matrices of one batch stay below ~48 GB
         const int W = a->par.realign_width;
-        const int P = std::max(64, ((2 * W + 1 + 63) / 64) * 64);
+        const int P = std::max(64, ((W + 1 + 63) / 64) * 64);  // typical anti-diagonal footprint is about half the band
         size_t q0 = 0;
         while (q0 < need.size()) {
             size_t q1 = q0;
             double bytes = 0;
             while (q1 < need.size()) {
                 double add = 0;
-                for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + sstates[q1].size() + 1) * P * 18.0;
+                for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + sstates[q1].size() + 1) * P * 26.0;
                 if (q1 > q0 && bytes + add > 48e9) break;
                 bytes += add; q1++;
             }

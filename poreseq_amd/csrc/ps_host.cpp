@@ -65,13 +65,13 @@ int runtime(Runtime** out) {
     return PS_OK;
 }
 
-void prof_begin(Runtime* rt) { if (rt->prof_on) hipEventRecord(rt->ev0, rt->stream); }
+void prof_begin(Runtime* rt) { if (rt->prof_on) (void)hipEventRecord(rt->ev0, rt->stream); }
 void prof_end(Runtime* rt, const char* name, double bytes) {
     if (!rt->prof_on) return;
-    hipEventRecord(rt->ev1, rt->stream);
-    hipEventSynchronize(rt->ev1);
+    (void)hipEventRecord(rt->ev1, rt->stream);
+    (void)hipEventSynchronize(rt->ev1);
     float ms = 0;
-    hipEventElapsedTime(&ms, rt->ev0, rt->ev1);
+    (void)hipEventElapsedTime(&ms, rt->ev0, rt->ev1);
     Prof& p = rt->prof[name];
     p.ms += ms; p.launches += 1; p.bytes += bytes;
 }
@@ -104,20 +104,22 @@ std::string apply_edit(const std::string& b, const Mut& m) {
 
 // ------------------------------------------------------------------------------------------ batch
 int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int ndir_, int lb_extra, bool matrices) {
+    (void)matrices;
     ndir = ndir_;
     const int W = a->par.realign_width;
     if (W < 0) return fail(PS_ERR_BAD_ARG, "realign_width < 0");
-    P = std::max(64, ((2 * W + 1 + 63) / 64) * 64);
-    if (P > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 511: band wider than one workgroup");
+    Pmax = std::max(64, ((2 * W + 1 + 63) / 64) * 64);
+    if (Pmax > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 511: band wider than one workgroup");
+    P = 0;
     jobs.clear();
     maxS = 0; maxC = 0; maxn = 0; maxlbn = 0;
-    int64_t st_tot = 0, lb_tot = 0, lo_tot = 0, mat_tot = 0, col_tot = 0;
+    int64_t st_tot = 0, lb_tot = 0, lo_tot = 0, col_tot = 0;
     std::vector<int> h_states;
     std::map<const std::vector<int>*, int64_t> st_seen;
     for (const JobSpec& s : specs) {
         JobD j;
         memset(&j, 0, sizeof(j));
-        j.ev = s.ev; j.n0 = a->n[s.ev]; j.C = (int)s.states->size(); j.W = W; j.P = P;
+        j.ev = s.ev; j.n0 = a->n[s.ev]; j.C = (int)s.states->size(); j.W = W; j.P = 0;
         j.force_inert = (W == 0) ? 1 : 0;
         j.lbn = j.C + 2 + lb_extra;
         j.lev_off = a->off[s.ev];
@@ -131,7 +133,6 @@ int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int n
         j.lbn_off = lb_tot; lb_tot += j.lbn;
         j.S = (int64_t)j.n0 + j.C + 1;
         for (int d = 0; d < ndir; d++) {
-            j.mat_off[d] = mat_tot; if (matrices) mat_tot += j.S * P;
             j.lo_off[d] = lo_tot; lo_tot += j.S;
             j.col_off[d] = col_tot; col_tot += j.C + 1;
         }
@@ -139,29 +140,44 @@ int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int n
         maxS = std::max(maxS, j.S); maxC = std::max(maxC, j.C); maxn = std::max(maxn, j.n0); maxlbn = std::max(maxlbn, j.lbn);
         jobs.push_back(j);
     }
+    ncols = col_tot;
     PS_TRY(rt->buf("jobs").ensure(jobs.size() * sizeof(JobD)));
     PS_TRY(rt->buf("states").ensure(std::max<size_t>(h_states.size(), 1) * sizeof(int)));
     PS_TRY(rt->buf("lb").ensure(std::max<int64_t>(lb_tot, 1) * sizeof(int)));
     PS_TRY(rt->buf("lo").ensure(std::max<int64_t>(lo_tot, 1) * sizeof(int)));
-    PS_TRY(rt->buf("rec").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double2)));
-    PS_TRY(rt->buf("flg").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short)));
     PS_TRY(rt->buf("cmax").ensure(std::max<int64_t>(col_tot, 1) * sizeof(double)));
-    PS_TRY(rt->buf("cmaxrow").ensure(std::max<int64_t>(col_tot, 1) * sizeof(int)));
     PS_TRY(rt->buf("pm").ensure(std::max<int64_t>(col_tot, 1) * sizeof(double)));
     PS_HIP(hipMemcpyAsync(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD), hipMemcpyHostToDevice, rt->stream));
     if (!h_states.empty())
         PS_HIP(hipMemcpyAsync(rt->buf("states").p, h_states.data(), h_states.size() * sizeof(int), hipMemcpyHostToDevice, rt->stream));
     PS_HIP(hipStreamSynchronize(rt->stream));  // the staging vectors die with this scope
-    cells = mat_tot;
     d.jobs = rt->buf("jobs").as<JobD>();
     d.njobs = (int)jobs.size();
     d.mean = a->d_mean; d.stdv = a->d_stdv; d.logstdv = a->d_lsd; d.model = a->d_model; d.trans = a->d_trans;
     d.states = rt->buf("states").as<int>();
     d.lb = rt->buf("lb").as<int>(); d.lo = rt->buf("lo").as<int>();
-    d.rec = rt->buf("rec").as<double2>(); d.flg = rt->buf("flg").as<unsigned short>();
-    d.cmax = rt->buf("cmax").as<double>(); d.cmaxrow = rt->buf("cmaxrow").as<int>(); d.pm = rt->buf("pm").as<double>();
+    d.rec = nullptr; d.em = nullptr; d.flg = nullptr;
+    d.cmax = rt->buf("cmax").as<double>(); d.pm = rt->buf("pm").as<double>();
     d.lik_offset = a->par.lik_offset;
     d.log2pi = std::log(2 * M_PI);  // cpp/AlignUtil.h:24
+    return PS_OK;
+}
+
+// second phase: the anti-diagonal footprint of every band is known, size the skewed matrices
+int Batch::place(Runtime* rt, int P_) {
+    P = std::min(Pmax, std::max(64, ((P_ + 63) / 64) * 64));
+    int64_t mat_tot = 0;
+    for (JobD& j : jobs) {
+        j.P = P;
+        for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot; mat_tot += j.S * P; }
+    }
+    cells = mat_tot;
+    PS_TRY(rt->buf("rec").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double2)));
+    PS_TRY(rt->buf("em").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double)));
+    PS_TRY(rt->buf("flg").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short)));
+    PS_HIP(hipMemcpyAsync(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD), hipMemcpyHostToDevice, rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    d.rec = rt->buf("rec").as<double2>(); d.em = rt->buf("em").as<double>(); d.flg = rt->buf("flg").as<unsigned short>();
     return PS_OK;
 }
 
@@ -178,7 +194,7 @@ double Batch::fill_alg_bytes(const Align* a) const {
 
 // ------------------------------------------------------------------------------------------ AlignData
 Align::~Align() {
-    if (slab) hipFree(slab);
+    if (slab) (void)hipFree(slab);
 }
 
 int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_events, const int64_t* level_off,
@@ -272,11 +288,18 @@ int Align::refs_to_host(Runtime* rt) {
 // cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
 int realign(Runtime* rt, Align* a, Batch& b, int lb_extra_ready) {
     (void)lb_extra_ready;
+    if (!b.d.njobs) return PS_OK;
     PS_TRY(launch_begin(rt, b.d));
     PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
+    PS_TRY(launch_lo(rt, b.d, b.ndir, b.maxS));
+    std::vector<JobOut> o(b.d.njobs);
+    PS_HIP(hipMemcpyAsync(o.data(), b.d.out, o.size() * sizeof(JobOut), hipMemcpyDeviceToHost, rt->stream));
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    int w = 1;
+    for (const JobOut& x : o) w = std::max(w, x.maxw);
+    PS_TRY(b.place(rt, w));
     if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes(a);
-    PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P));
-    PS_TRY(launch_colstats(rt, b.d, b.ndir, b.maxC));
+    PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P, b.ncols));
     PS_TRY(launch_backtrace(rt, b.d, b.maxn));
     PS_TRY(launch_updaterefs(rt, b.d));
     return PS_OK;

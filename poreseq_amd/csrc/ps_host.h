@@ -20,9 +20,10 @@ struct JobSpec {
 struct Batch {
     std::vector<JobD> jobs;
     BatchD d;
-    int ndir = 1, P = 64, maxC = 0, maxn = 0, maxlbn = 0;
-    int64_t maxS = 0, cells = 0;
+    int ndir = 1, P = 0, Pmax = 64, maxC = 0, maxn = 0, maxlbn = 0;
+    int64_t maxS = 0, cells = 0, ncols = 0;
     int build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int ndir, int lb_extra, bool matrices = true);
+    int place(Runtime* rt, int P);
     double fill_alg_bytes(const Align* a) const;
 };
 

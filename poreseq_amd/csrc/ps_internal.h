@@ -99,6 +99,8 @@ struct JobOut {
     int has_index;    // ref_index non-empty after the latest updaterefs
     int refstart, refend;
     int inert;        // latched at the start of an API call: the reference's stripe_width == 0
+    int maxw;         // widest band footprint on one anti-diagonal (sizes P)
+    int pad;
 };
 
 // device pointers of everything a batch of jobs needs (filled by Batch::upload)
@@ -112,10 +114,10 @@ struct BatchD {
     const int* states;                    // pool
     int* lb;                              // pool of lb tables
     int* lo;                              // pool
-    double2* rec;                         // matrices
+    double2* rec;                         // matrices {main, stay}
+    double* em;                           // emission log-densities, same skewed layout
     unsigned short* flg;
     double* cmax;                         // per column max of main
-    int* cmaxrow;                         // first row achieving it
     double* pm;                           // prefix max over columns (MaxInfo.score per column)
     double lik_offset;
     double log2pi;
@@ -124,8 +126,8 @@ struct BatchD {
 // ---- kernel launchers (ps_kernels.hip) ------------------------------------------------------
 int launch_updaterefs(Runtime* rt, const BatchD& b);
 int launch_lb(Runtime* rt, const BatchD& b, int which /*0: lb_off, 1: lbn_off*/, int maxlbn);
-int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P);
-int launch_colstats(Runtime* rt, const BatchD& b, int ndir, int maxC);
+int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS);
+int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols);
 int launch_backtrace(Runtime* rt, const BatchD& b, int maxn);
 
 struct ScoreArgs {

@@ -24,7 +24,8 @@
 
 namespace ps {
 
-enum : unsigned { F_ACT = 1, F_VL = 2, F_VD = 4, F_TOP = 8, F_INV = 16, F_BLANK = 32 };
+enum : unsigned { F_ACT = 1, F_VL = 2, F_VD = 4, F_TOP = 8, F_INV = 16, F_BLANK = 32,
+                  F_RL = 64 /* left value is a real stored cell */, F_RD = 128 /* diagonal value is a real stored cell */ };
 enum : unsigned { M_SKIP = 0, M_MATCH = 1, M_INSERT = 2, M_IGNORE = 3, M_STAY = 4, M_EXTEND = 5, M_IMPL = 255 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -129,35 +130,51 @@ __global__ void k_lb(BatchD b, int which) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// lo[s]: lowest in-band row on anti-diagonal s  (-1: none).  The rows of s are s - j for the
-// columns j with i0(j) + j <= s <= i1(j) + j, a contiguous column range; lo = s - jhi.
+// lo[s]: lowest in-band row on anti-diagonal s (-1: none) and the footprint width of the band on s.
+// The columns present on s are those with i0(j) + j <= s <= i1(j) + j — a contiguous range
+// [jlo, jhi] because both bounds are strictly increasing in j; rows are s - j, so lo = s - jhi and
+// width = jhi - jlo + 1 <= 2W + 1.  The per-job maximum width sizes P (slots per anti-diagonal).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_lo(BatchD b, int ndir) {
+__global__ __launch_bounds__(256) void k_lo(BatchD b, int ndir) {
     const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
+    if (b.out[job].inert) return;
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= J.S || b.out[job].inert) return;
-    const int* lb = b.lb + J.lb_off;
-    int* LO = b.lo + J.lo_off[dir];
-    int res = -1;
-    if (J.C >= 1) {
-        int i0, i1;
-        band_of(lb, dir, 1, J.C, J.n0, J.W, i0, i1);
-        if (i0 + 1 <= s) {
-            int lo = 1, hi = J.C;  // invariant: f(lo) <= s
-            while (lo < hi) {
-                int mid = (lo + hi + 1) >> 1;
-                band_of(lb, dir, mid, J.C, J.n0, J.W, i0, i1);
-                if ((int64_t)i0 + mid <= s) lo = mid; else hi = mid - 1;
+    int width = 0;
+    if (s < J.S) {
+        const int* lb = b.lb + J.lb_off;
+        int res = -1;
+        if (J.C >= 1) {
+            int i0, i1;
+            band_of(lb, dir, 1, J.C, J.n0, J.W, i0, i1);
+            if (i0 + 1 <= s) {
+                int lo = 1, hi = J.C;  // largest j with i0(j) + j <= s
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    band_of(lb, dir, mid, J.C, J.n0, J.W, i0, i1);
+                    if ((int64_t)i0 + mid <= s) lo = mid; else hi = mid - 1;
+                }
+                const int jhi = lo;
+                band_of(lb, dir, J.C, J.C, J.n0, J.W, i0, i1);
+                if ((int64_t)i1 + J.C >= s) {
+                    lo = 1; hi = J.C;  // smallest j with i1(j) + j >= s
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        band_of(lb, dir, mid, J.C, J.n0, J.W, i0, i1);
+                        if ((int64_t)i1 + mid >= s) hi = mid; else lo = mid + 1;
+                    }
+                    if (lo <= jhi) { res = (int)(s - jhi); width = jhi - lo + 1; }
+                }
             }
-            res = (int)(s - lo);
         }
+        (b.lo + J.lo_off[dir])[s] = res;
     }
-    LO[s] = res;
+    for (int off = 32; off; off >>= 1) width = max(width, __shfl_xor(width, off));
+    if ((threadIdx.x & 63) == 0 && width > 0) atomicMax(&b.out[job].maxw, width);
 }
 
 // ------------------------------------------------------------------------------------------------
-// emission pass: for every (s, slot) write REC.x = emission (or 0) and FLG = band flags
+// emission pass: for every (s, slot) write EM = emission (or 0) and FLG = band flags
 // grid (nblk, njobs*ndir), block 256; the event's 48 KB model is staged in LDS
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
     const double* __restrict__ mean = b.mean + J.lev_off;
     const double* __restrict__ stdv = b.stdv + J.lev_off;
     const double* __restrict__ lsdv = b.logstdv + J.lev_off;
-    double2* __restrict__ rec = b.rec + J.mat_off[dir];
+    double* __restrict__ em = b.em + J.mat_off[dir];
     unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
     const int64_t ncell = J.S * P;
     for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < ncell; cell += (int64_t)gridDim.x * 256) {
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
         double e = 0.0;
         const int lo = LO[s];
         if (lo >= 0) {
-            int d = (slot - lo % P + P) % P;
+            const int d = (slot - lo % P + P) % P;
             const int i = lo + d, j = s - i;
             if (i <= n0 && j >= 1 && j <= C) {
                 int i0, i1;
@@ -194,8 +211,8 @@ __global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
                     int p0, p1;
                     if (j == 1) { p0 = 0; p1 = n0; f |= F_BLANK; }
                     else band_of(lb, dir, j - 1, C, n0, W, p0, p1);
-                    if (i >= p0 && i <= p1) f |= F_VL;
-                    if (i > p0 && i <= p1) f |= F_VD;
+                    if (i >= p0 && i <= p1) f |= F_VL | (j == 1 ? 0u : F_RL);
+                    if (i > p0 && i <= p1) f |= F_VD | (j == 1 ? 0u : F_RD);
                     if (i == i0) f |= F_TOP;
                     const int state = st[dir == 0 ? j - 1 : C - j];
                     if (state < 0) {
@@ -210,13 +227,18 @@ __global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
                 }
             }
         }
-        rec[cell] = make_double2(e, 0.0);
+        em[cell] = e;
         flg[cell] = (unsigned short)f;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// recurrence pass: one workgroup (P lanes) per (job, direction)
+// recurrence pass: one workgroup (P lanes) per (job, direction).  Values only: the maximum over the
+// candidate moves equals the reference's ordered strict-'>' selection (cpp/Alignment.cpp:240-267)
+// whatever the tie order, so plain fmax is exact; the step codes are derived afterwards by k_steps.
+// A lane that has no in-band cell on an anti-diagonal holds zeros, which is exactly the reference's
+// "implicit zero" for neighbours outside the previous band (cpp/Alignment.cpp:201-225); a missing
+// upper neighbour (top row of a band) is -infinity for the stay / extend / insert moves.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_shr1(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -232,10 +254,12 @@ __device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, doubl
     const int P = J.P, slot = threadIdx.x, lane = slot & 63, wave = slot >> 6, NW = P >> 6;
     const int wprev = (wave + NW - 1) % NW;
     const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
+    const double* __restrict__ em = b.em + J.mat_off[DIR];
+    const unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR];
     double2* __restrict__ rec = b.rec + J.mat_off[DIR];
-    unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR];
     const int64_t S = J.S;
-    double cm = 0.0, cs = 0.0, co = 0.0;   // this lane's latest main / stay / emission
+    const double NINF = -__builtin_inf();
+    double cm = 0.0, cs = 0.0, co = 0.0;   // this lane's latest main / stay / emission (0 when it had no cell)
     double upm = 0.0, upo = 0.0;           // what the upper neighbour handed over one step ago
     int par = 0;
     if (lane == 63) { xch[0][wave][0] = 0.0; xch[0][wave][1] = 0.0; xch[0][wave][2] = 0.0; }
@@ -246,14 +270,14 @@ __device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, doubl
 #pragma unroll
     for (int u = 0; u < PF; u++) {
         const int64_t s = 2 + u;
-        e_cur[u] = s < S ? rec[s * P + slot].x : 0.0;
+        e_cur[u] = s < S ? em[s * P + slot] : 0.0;
         f_cur[u] = s < S ? flg[s * P + slot] : 0u;
     }
     for (int64_t s0 = 2; s0 < S; s0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int64_t s = s0 + PF + u;
-            e_nxt[u] = s < S ? rec[s * P + slot].x : 0.0;
+            e_nxt[u] = s < S ? em[s * P + slot] : 0.0;
             f_nxt[u] = s < S ? flg[s * P + slot] : 0u;
         }
 #pragma unroll
@@ -261,48 +285,45 @@ __device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, doubl
             const int64_t s = s0 + u;
             if (s < S) {  // uniform over the workgroup
                 const unsigned f = f_cur[u];
-                double um = wave_shr1(cm), us = wave_shr1(cs), uo = 0.0;
-                if (DIR) uo = wave_shr1(co);
-                if (lane == 0) { um = xch[par][wprev][0]; us = xch[par][wprev][1]; if (DIR) uo = xch[par][wprev][2]; }
-                double D = upm, L = cm;
-                const double pobs = upo;
-                upm = um;
-                if (DIR) upo = uo;
-                if (f & F_ACT) {
-                    double nm = 0.0, ns = 0.0;
-                    unsigned sm = 0, ss = 0;
-                    double o = 0.0;
-                    if (!(f & F_INV)) {
-                        o = e_cur[u];
-                        double po = pobs;
-                        if (f & F_BLANK) { L = 0.0; D = 0.0; po = 0.0; }
-                        const bool vl = f & F_VL, vd = f & F_VD;
-                        const double cSKIP = vl ? L + lsk : lsk;
-                        const unsigned kSKIP = vl ? M_SKIP : M_IMPL;
-                        double cMATCH;
-                        if (DIR == 0) cMATCH = vd ? D + o : o; else cMATCH = vd ? D + po : 0.0;
-                        const unsigned kMATCH = vd ? M_MATCH : M_IMPL;
-                        const double cIGN = vd ? D + lin : 0.0;
-                        double cSTAY = -BIG, cEXT = -BIG, cINS = 0.0;
-                        if (f & F_TOP) {
-                            ns = -BIG;
-                        } else {
-                            const double eo = DIR == 0 ? o : uo;
-                            cSTAY = um + eo + lst;
-                            cINS = um + lin;
-                            cEXT = us + eo + lex;
-                        }
-                        if (cSTAY > ns) { ns = cSTAY; ss = M_STAY; }
-                        if (cEXT > ns) { ns = cEXT; ss = M_EXTEND; }
-                        if (cSKIP > nm) { nm = cSKIP; sm = kSKIP; }
-                        if (cMATCH > nm) { nm = cMATCH; sm = kMATCH; }
-                        if (cINS > nm) { nm = cINS; sm = M_INSERT; }
-                        if (cIGN > nm) { nm = cIGN; sm = M_IGNORE; }
-                        if (ns > nm) { nm = ns; sm = M_STAY; }
-                    }
-                    cm = nm; cs = ns; co = o;
-                    rec[s * P + slot] = make_double2(nm, ns);
-                    flg[s * P + slot] = (unsigned short)(sm | (ss << 8));
+                const bool act = f & F_ACT;
+                if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+                    double um = wave_shr1(cm), us = wave_shr1(cs), uo = 0.0;
+                    if (DIR) uo = wave_shr1(co);
+                    if (lane == 0) { um = xch[par][wprev][0]; us = xch[par][wprev][1]; if (DIR) uo = xch[par][wprev][2]; }
+                    // a lane can have served row i - P one step earlier: gate the left / diagonal inputs explicitly
+                    const double L = (f & F_RL) ? cm : 0.0;
+                    const double D = (f & F_RD) ? upm : 0.0;
+                    const double po = (f & F_RD) ? upo : 0.0;
+                    upm = um;
+                    if (DIR) upo = uo;
+                    const bool top = f & F_TOP;
+                    const double ume = top ? NINF : um, use = top ? NINF : us;
+                    const double o = e_cur[u];
+                    const double eo = DIR == 0 ? o : uo;
+                    const double cSTAY = ume + eo + lst;
+                    const double cEXT = use + eo + lex;
+                    const double cINS = ume + lin;
+                    const double cSKIP = L + lsk;
+                    const double cMATCH = DIR == 0 ? D + o : D + po;
+                    const double cIGN = D + lin;
+                    double ns = top ? -BIG : 0.0;
+                    ns = fmax(ns, cSTAY);
+                    ns = fmax(ns, cEXT);
+                    double nm = fmax(0.0, cSKIP);
+                    nm = fmax(nm, cMATCH);
+                    nm = fmax(nm, cINS);
+                    nm = fmax(nm, cIGN);
+                    nm = fmax(nm, ns);
+                    const bool live = act && !(f & F_INV);
+                    cm = live ? nm : 0.0;
+                    cs = live ? ns : 0.0;
+                    if (DIR) co = live ? o : 0.0;
+                    if (act) rec[s * P + slot] = make_double2(cm, cs);
+                } else {
+                    // no cell for this wave on this anti-diagonal: keep the hand-over chain alive
+                    upm = 0.0; upo = 0.0;
+                    if (lane == 0) { upm = xch[par][wprev][0]; if (DIR) upo = xch[par][wprev][2]; }
+                    cm = 0.0; cs = 0.0; co = 0.0;
                 }
                 if (lane == 63) { xch[par ^ 1][wave][0] = cm; xch[par ^ 1][wave][1] = cs; if (DIR) xch[par ^ 1][wave][2] = co; }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -323,33 +344,99 @@ __global__ __launch_bounds__(1024) void k_recur(BatchD b, int ndir) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-column max of the main matrix (-> MaxInfo per column) ; grid (maxC, njobs*ndir), block 64
+// step / statistics pass, chip-wide and coalesced in the skewed layout:
+//   * forward direction: re-derive each cell's back-pointer codes with the reference's ordered
+//     strict-'>' selection from the stored neighbour values (cpp/Alignment.cpp:196-267)
+//   * both directions: per-column maximum of the main matrix (-> MaxInfo per column), aggregated in
+//     LDS per block of SB anti-diagonals, then one global atomic max per touched column
+// grid (ceil(maxS / SB), njobs*ndir), block 256
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_colstats(BatchD b, int ndir) {
+constexpr int SB = 32;
+constexpr int SCOLS = 2048;
+
+__global__ __launch_bounds__(256) void k_steps(BatchD b, int ndir) {
+    __shared__ unsigned long long s_cmax[SCOLS];
+    __shared__ int s_jbase, s_ok;
     const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
-    const int c = blockIdx.x + 1;
-    if (c > J.C) return;
-    double best = 0.0;
-    int brow = 0;
-    if (!b.out[job].inert) {
-        const int* lb = b.lb + J.lb_off;
-        const double2* __restrict__ rec = b.rec + J.mat_off[dir];
-        int i0, i1;
-        band_of(lb, dir, c, J.C, J.n0, J.W, i0, i1);
-        double v = 0.0; int r = 0x7fffffff;
-        for (int i = i0 + (int)threadIdx.x; i <= i1; i += 64) {
-            const double x = rec[(int64_t)(i + c) * J.P + slot_of(i, J.P)].x;
-            if (x > v) { v = x; r = i; }
+    if (b.out[job].inert) return;
+    const int64_t s0 = (int64_t)blockIdx.x * SB;
+    if (s0 >= J.S) return;
+    const int nst = (int)min((int64_t)SB, J.S - s0);
+    const int P = J.P;
+    const int* __restrict__ LO = b.lo + J.lo_off[dir];
+    if (threadIdx.x == 0) {
+        int jmin = 0x7fffffff, jmax = -1;
+        for (int k = 0; k < nst; k++) {
+            const int lo = LO[s0 + k];
+            if (lo < 0) continue;
+            const int s = (int)(s0 + k);
+            jmax = max(jmax, s - lo);
+            jmin = min(jmin, s - lo - P + 1);
         }
-        for (int off = 32; off; off >>= 1) {
-            const double ov = __shfl_xor(v, off);
-            const int orow = __shfl_xor(r, off);
-            if (ov > v || (ov == v && orow < r)) { v = ov; r = orow; }
-        }
-        best = v; brow = (r == 0x7fffffff) ? 0 : r;
+        s_jbase = jmin;
+        s_ok = (jmax >= 0 && jmax - jmin + 1 <= SCOLS) ? 1 : (jmax < 0 ? -1 : 0);
     }
-    if (threadIdx.x == 0) { b.cmax[J.col_off[dir] + c] = best; b.cmaxrow[J.col_off[dir] + c] = brow; }
+    for (int k = threadIdx.x; k < SCOLS; k += 256) s_cmax[k] = 0ull;
+    __syncthreads();
+    if (s_ok < 0) return;  // nothing in band on these anti-diagonals
+    const bool use_lds = s_ok == 1;
+    const int jbase = s_jbase;
+    const double2* __restrict__ rec = b.rec + J.mat_off[dir];
+    const double* __restrict__ em = b.em + J.mat_off[dir];
+    unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
+    unsigned long long* gcmax = (unsigned long long*)(b.cmax + J.col_off[dir]);
+    const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
+    for (int idx = threadIdx.x; idx < nst * P; idx += 256) {
+        const int k = idx / P, slot = idx - k * P;
+        const int64_t s = s0 + k;
+        const int64_t cell = s * P + slot;
+        const unsigned f = flg[cell];
+        if (!(f & F_ACT)) continue;
+        const int lo = LO[s];
+        const int i = lo + (slot - lo % P + P) % P;
+        const int j = (int)s - i;
+        const double2 v = rec[cell];
+        if (v.x > 0.0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v.x);
+            if (use_lds) atomicMax(&s_cmax[j - jbase], bits); else atomicMax(&gcmax[j], bits);
+        }
+        if (dir == 0) {
+            unsigned sm = 0, ss = 0;
+            if (!(f & F_INV)) {
+                const int sm1 = slot == 0 ? P - 1 : slot - 1;
+                const double o = em[cell];
+                double L = 0.0, D = 0.0, um = 0.0, us = 0.0;
+                const bool blank = f & F_BLANK, vl = f & F_VL, vd = f & F_VD, top = f & F_TOP;
+                if (vl && !blank) L = rec[cell - P].x;
+                if (vd && !blank) D = rec[(s - 2) * P + sm1].x;
+                if (!top) { const double2 u = rec[(s - 1) * P + sm1]; um = u.x; us = u.y; }
+                const double cSKIP = vl ? L + lsk : lsk;
+                const unsigned kSKIP = vl ? M_SKIP : M_IMPL;
+                const double cMATCH = vd ? D + o : o;
+                const unsigned kMATCH = vd ? M_MATCH : M_IMPL;
+                const double cIGN = vd ? D + lin : 0.0;
+                double cSTAY = -BIG, cEXT = -BIG, cINS = 0.0, ns = 0.0, nm = 0.0;
+                if (top) ns = -BIG;
+                else { cSTAY = um + o + lst; cINS = um + lin; cEXT = us + o + lex; }
+                if (cSTAY > ns) { ns = cSTAY; ss = M_STAY; }
+                if (cEXT > ns) { ns = cEXT; ss = M_EXTEND; }
+                if (cSKIP > nm) { nm = cSKIP; sm = kSKIP; }
+                if (cMATCH > nm) { nm = cMATCH; sm = kMATCH; }
+                if (cINS > nm) { nm = cINS; sm = M_INSERT; }
+                if (cIGN > nm) { nm = cIGN; sm = M_IGNORE; }
+                if (ns > nm) { nm = ns; sm = M_STAY; }
+            }
+            flg[cell] = (unsigned short)(sm | (ss << 8));
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < SCOLS; k += 256) {
+            const unsigned long long v = s_cmax[k];
+            if (v) atomicMax(&gcmax[jbase + k], v);
+        }
+    }
 }
 
 // prefix max over columns + (fwd) the first cell achieving the global max ; grid njobs*ndir, block 64
@@ -379,10 +466,20 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
             for (int c = 1 + lane; c <= J.C; c += 64)
                 if (cmax[c] == best) { bj = c; break; }
         for (int off = 32; off; off >>= 1) bj = min(bj, __shfl_xor(bj, off));
+        int bi = 0x7fffffff;
+        if (best > 0.0) {  // first row of that column holding the maximum (row-ascending visit order)
+            const int* lb = b.lb + J.lb_off;
+            const double2* __restrict__ rec = b.rec + J.mat_off[0];
+            int i0, i1;
+            band_of(lb, 0, bj, J.C, J.n0, J.W, i0, i1);
+            for (int i = i0 + lane; i <= i1; i += 64)
+                if (rec[(int64_t)(i + bj) * J.P + slot_of(i, J.P)].x == best) { bi = i; break; }
+            for (int off = 32; off; off >>= 1) bi = min(bi, __shfl_xor(bi, off));
+        }
         if (lane == 0) {
             JobOut* O = b.out + job;
             O->best = best;
-            if (best > 0.0) { O->bj = bj; O->bi = b.cmaxrow[J.col_off[0] + bj]; }
+            if (best > 0.0) { O->bj = bj; O->bi = bi; }
             else { O->bj = 0; O->bi = 0; }
         }
     }
@@ -648,7 +745,7 @@ __global__ void k_begin(BatchD b) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= b.njobs) return;
     b.out[j].inert = (b.jobs[j].force_inert || !b.out[j].has_index) ? 1 : 0;
-    b.out[j].best = 0.0; b.out[j].bi = 0; b.out[j].bj = 0;
+    b.out[j].best = 0.0; b.out[j].bi = 0; b.out[j].bj = 0; b.out[j].maxw = 0;
 }
 
 // =================================================================================================
@@ -671,10 +768,15 @@ int launch_lb(Runtime* rt, const BatchD& b, int which, int maxlbn) {
     return PS_OK;
 }
 
-int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P) {
+int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS) {
     if (!b.njobs) return PS_OK;
     hipLaunchKernelGGL(k_lo, dim3((unsigned)((maxS + 255) / 256), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols) {
+    if (!b.njobs) return PS_OK;
     int nblk = (int)std::min<int64_t>((maxS * P + 256 * 16 - 1) / (256 * 16), std::max(16, 4096 / (b.njobs * ndir)));
     nblk = std::max(nblk, 1);
     hipLaunchKernelGGL(k_emis, dim3(nblk, b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
@@ -683,12 +785,8 @@ int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P) {
     hipLaunchKernelGGL(k_recur, dim3(b.njobs * ndir), dim3(P), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     prof_end(rt, "fill", 0.0);
-    return PS_OK;
-}
-
-int launch_colstats(Runtime* rt, const BatchD& b, int ndir, int maxC) {
-    if (!b.njobs || maxC < 1) return PS_OK;
-    hipLaunchKernelGGL(k_colstats, dim3(maxC, b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
+    PS_HIP(hipMemsetAsync(b.cmax, 0, ncols * sizeof(double), rt->stream));
+    hipLaunchKernelGGL(k_steps, dim3((unsigned)((maxS + SB - 1) / SB), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_prefix, dim3(b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();

@@ -76,8 +76,10 @@ def test_dp_matrices_bit_exact(L, E, seed, par):
                 h = api.align_create(draft, copy.deepcopy(events), par)
                 outs.append(api.debug_fill(h, e, d, events[e].mean.size, len(draft) - 4))
                 api.align_destroy(h)
-            for x, y in zip(*outs):
-                assert np.array_equal(x, y, equal_nan=True), (d, e)
+            for k, (x, y) in enumerate(zip(*outs)):
+                if d == 1 and k >= 2:
+                    continue   # backward step codes are not kept (nothing reads them)
+                assert np.array_equal(x, y, equal_nan=True), (d, e, k)
 
 
 @pytest.mark.parametrize("L,E,seed,par", [
