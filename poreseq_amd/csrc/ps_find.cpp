@@ -30,7 +30,9 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
     const size_t L = a->bases.size();
     // re-align to the current sequence, keeping per-base cumulative likelihoods (cpp/FindMutations.cpp:28-29)
     std::vector<double> base(std::max<size_t>(L, 4) + 1, 0.0), sc(std::max(a->E, 1));
+    Tick tk("find_mutations");
     PS_TRY(score_alignments(rt, a, sc.data(), base.data()));
+    tk.lap("base realign");
     const int S = (int)seeds.size();
     if (!S) return PS_OK;
     // Smith-Waterman of the current sequence against every seed (MapAlignments, cpp/EventUtil.cpp:16)
@@ -39,6 +41,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
     std::vector<SwResult> als;
     PS_TRY(sw_batch(rt, pairs, &als));
     for (SwResult& al : als) fillinds(al);
+    tk.lap("smith-waterman");
     // seeds whose likelihood vector is not cached yet get (seed x event) alignment jobs
     std::vector<int> need;
     {
@@ -83,6 +86,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
                     dst[t] = v;
                 }
             }
+            tk.lap("remap (host)");
             DBuf& rb = rt->buf("seed_refs");
             PS_TRY(rb.ensure((size_t)3 * ns * std::max<int64_t>(a->ntot, 1) * sizeof(double)));
             double* d_ra = rb.as<double>();
@@ -106,11 +110,15 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             PS_TRY(b.build(rt, a, specs, 1, 0));
             b.d.out = ob.as<JobOut>();
             PS_TRY(launch_updaterefs(rt, b.d));  // MapAlignments ends with updaterefs (cpp/EventUtil.cpp:51)
+            tk.lap("seed batch build");
             PS_TRY(realign(rt, a, b, 0));
+            PS_HIP(hipStreamSynchronize(rt->stream));
+            tk.lap("seed realign");
             std::vector<double> r_ra(ns * a->ntot), r_rl(ns * a->ntot);
             PS_HIP(hipMemcpyAsync(r_ra.data(), d_ra, r_ra.size() * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
             PS_HIP(hipMemcpyAsync(r_rl.data(), d_rl, r_rl.size() * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
             PS_HIP(hipStreamSynchronize(rt->stream));
+            tk.lap("seed D2H");
             for (size_t q = q0; q < q1; q++) {
                 const std::string& sd = seeds[need[q]];
                 std::vector<double> lk(std::max<size_t>(sd.size(), 4) + 1, 0.0);
@@ -126,6 +134,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
     } else if (!need.empty()) {
         for (int k : need) a->seqlikes[seeds[k]] = std::vector<double>(seeds[k].size(), 0.0);
     }
+    tk.lap("seed likes");
     // per seed: likelihood differences along the pairwise alignment -> clamped CUSUM (cpp/FindMutations.cpp:51-98)
     std::vector<std::vector<double>> dl(S);
     for (int k = 0; k < S; k++) {
@@ -151,14 +160,43 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             if (std::fabs(x[q] - y[q]) < 1e-5) cs[q] = 0;
         }
     }
-    // greedy extraction of candidate edits (cpp/FindMutations.cpp:111-183)
+    tk.lap("cusum");
+    // greedy extraction of candidate edits (cpp/FindMutations.cpp:111-183).  The reference rescans every
+    // seed's vector for its maximum on each round; here per-seed block maxima (128 entries per block)
+    // are kept current instead — same first-maximum semantics (std::max_element), same output.
+    const size_t BLK = 128;
+    std::vector<std::vector<double>> bmax(S);
+    auto block_refresh = [&](int k, size_t blk) {
+        const std::vector<double>& v = dl[k];
+        const size_t lo = blk * BLK, hi = std::min(v.size(), lo + BLK);
+        double m = v[lo];
+        for (size_t q = lo + 1; q < hi; q++) if (v[q] > m) m = v[q];
+        bmax[k][blk] = m;
+    };
+    auto seed_argmax = [&](int k) -> int {   // index of the first maximum of dl[k]
+        const std::vector<double>& bm = bmax[k];
+        size_t bb = 0;
+        for (size_t q = 1; q < bm.size(); q++) if (bm[q] > bm[bb]) bb = q;
+        const std::vector<double>& v = dl[k];
+        const size_t lo = bb * BLK, hi = std::min(v.size(), lo + BLK);
+        size_t at = lo;
+        for (size_t q = lo + 1; q < hi; q++) if (v[q] > v[at]) at = q;
+        return (int)at;
+    };
+    std::vector<double> top(S, 0.0);
+    std::vector<int> topi(S, 0);
+    for (int k = 0; k < S; k++) {
+        if (dl[k].empty()) continue;
+        bmax[k].resize((dl[k].size() + BLK - 1) / BLK);
+        for (size_t blk = 0; blk < bmax[k].size(); blk++) block_refresh(k, blk);
+        topi[k] = seed_argmax(k);
+        top[k] = dl[k][topi[k]];
+    }
     while (out->size() < L / 3) {
-        std::vector<double> top(S, 0.0);
-        for (int k = 0; k < S; k++) top[k] = dl[k].empty() ? 0.0 : dl[k][argmax(dl[k])];
         const int w = argmax(top);
         std::vector<double>& v = dl[w];
         if (v.empty()) break;
-        const int ind = argmax(v);
+        const int ind = topi[w];
         if (v[ind] < 0.25) break;
         int i1 = (int)(std::find(v.begin() + ind, v.end(), 0.0) - v.begin());
         int i0 = -1;
@@ -180,7 +218,11 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
         while (!m.orig.empty() && !m.mut.empty() && m.orig.back() == m.mut.back()) { m.orig.pop_back(); m.mut.pop_back(); }
         if (!m.orig.empty() || !m.mut.empty()) out->push_back(m);
         std::fill(v.begin() + i0, v.begin() + i1 + 1, 0.0);
+        for (size_t blk = (size_t)i0 / BLK; blk <= (size_t)i1 / BLK; blk++) block_refresh(w, blk);
+        topi[w] = seed_argmax(w);
+        top[w] = v[topi[w]];
     }
+    tk.lap("extract");
     return PS_OK;
 }
 

@@ -10,12 +10,23 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <cstdio>
+#include <ctime>
 
 namespace ps {
 
 static thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 const char* last_error() { return g_err.c_str(); }
+
+static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+Tick::Tick(const char* w) : what(w), t0(now_s()) { static int e = getenv("PORESEQ_TRACE") ? 1 : 0; on = e; }
+void Tick::lap(const char* label) {
+    if (!on) return;
+    const double t = now_s();
+    fprintf(stderr, "[ps] %-18s %-22s %8.3f ms\n", what, label, 1e3 * (t - t0));
+    t0 = t;
+}
 
 // ------------------------------------------------------------------------------------------ runtime
 int DBuf::ensure(size_t bytes) {
@@ -175,6 +186,8 @@ int Batch::place(Runtime* rt, int P_) {
     PS_TRY(rt->buf("rec").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double2)));
     PS_TRY(rt->buf("em").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double)));
     PS_TRY(rt->buf("flg").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short)));
+    PS_TRY(rt->buf("dummy").ensure(jobs.size() * ndir * 1024 * sizeof(double2)));
+    d.dummy = rt->buf("dummy").as<double2>();
     PS_HIP(hipMemcpyAsync(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD), hipMemcpyHostToDevice, rt->stream));
     PS_HIP(hipStreamSynchronize(rt->stream));
     d.rec = rt->buf("rec").as<double2>(); d.em = rt->buf("em").as<double>(); d.flg = rt->buf("flg").as<unsigned short>();
@@ -365,6 +378,7 @@ static void edited_window(const std::string& b, const Mut& m, int sidx, int ncol
 
 // ScoreMutations, cpp/MakeMutations.cpp:23-69
 int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::vector<Mut>* out) {
+    Tick tk("score_mutations");
     *out = muts;
     for (Mut& m : *out) m.score = -1e-6;
     const int M = (int)muts.size();
@@ -416,6 +430,7 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
         const int nc = h_ncol[i];
         cls[nc <= 8 ? 0 : nc <= 16 ? 1 : nc <= 32 ? 2 : 3].push_back(i);
     }
+    tk.lap("edit geometry");
     Batch b;
     PS_TRY(a->base_batch(rt, &b, 2, extra));
     // upload edit tables
@@ -440,7 +455,10 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
     PS_TRY(db.ensure(dbl * sizeof(double)));
     sa.old = db.as<double>(); sa.delta = sa.old + (size_t)a->E * std::max(nr0, 1); sa.score = sa.delta + (size_t)a->E * std::max(M, 1);
     // Alignment::update for every event, then every edit against every event
+    tk.lap("upload");
     PS_TRY(realign(rt, a, b, extra));
+    if (tk.on) { PS_HIP(hipStreamSynchronize(rt->stream)); }
+    tk.lap("realign fwd+back");
     a->host_refs_valid = false;
     PS_TRY(launch_lb(rt, b.d, 1, b.maxlbn));
     if (M) {
@@ -457,6 +475,7 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
         PS_HIP(hipMemcpyAsync(sc.data(), sa.score, M * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
         PS_HIP(hipStreamSynchronize(rt->stream));
         for (int i = 0; i < M; i++) (*out)[i].score = sc[i];
+        tk.lap("score edits");
     } else {
         PS_HIP(hipStreamSynchronize(rt->stream));
     }
@@ -488,6 +507,7 @@ static bool by_score_desc(const Mut& x, const Mut& y) { return x.score > y.score
 // MakeMutations, cpp/MakeMutations.cpp:74-146.  std::sort with the same comparator on the same
 // libstdc++ gives the reference's (unstable) order for tied scores.
 int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {
+    Tick tk("make_mutations");
     const int spacing = 10;
     int nb = 0;
     std::sort(muts.begin(), muts.end(), by_score_desc);
@@ -509,6 +529,7 @@ int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {
         }
     }
     if (changed) a->states = states_of(a->bases);
+    tk.lap("greedy apply");
     if (later.size() > 10) {
         std::vector<Mut> rescored;
         PS_TRY(score_mutations(rt, a, later, &rescored));

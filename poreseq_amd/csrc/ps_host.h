@@ -8,6 +8,13 @@ namespace ps {
 
 const char* last_error();
 
+// PORESEQ_TRACE=1: wall-clock phase timers on stderr (host-side tuning aid)
+struct Tick {
+    const char* what; double t0; bool on;
+    explicit Tick(const char* w);
+    void lap(const char* label);
+};
+
 struct Align;
 
 struct JobSpec {

@@ -116,6 +116,7 @@ struct BatchD {
     int* lo;                              // pool
     double2* rec;                         // matrices {main, stay}
     double* em;                           // emission log-densities, same skewed layout
+    double2* dummy;                       // 1024 scratch records per workgroup: store target of lanes without a cell
     unsigned short* flg;
     double* cmax;                         // per column max of main
     double* pm;                           // prefix max over columns (MaxInfo.score per column)

@@ -247,92 +247,104 @@ __device__ __forceinline__ double wave_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
-constexpr int PF = 4;  // anti-diagonals of emission / flag prefetch kept in registers
+constexpr int PF = 4;  // anti-diagonals per prefetch group (two groups ping-pong in registers)
+
+template <int DIR>
+struct RecurState {
+    double cm = 0.0, cs = 0.0, co = 0.0;   // this lane's latest main / stay / emission (0 when it had no cell)
+    double upm = 0.0, upo = 0.0;           // what the upper neighbour handed over one step ago
+    int par = 0;
+};
+
+// one anti-diagonal.  Memory operations are unconditional (inactive lanes store to a private dummy
+// slot) so that hipcc can count vmcnt exactly and the prefetch of later anti-diagonals stays in flight.
+template <int DIR>
+__device__ __forceinline__ void recur_step(RecurState<DIR>& r, const double o, const unsigned f, double2* __restrict__ dst,
+                                           double (*xch)[16][4], const int lane, const int wave, const int wprev,
+                                           const double lsk, const double lst, const double lex, const double lin) {
+    const double NINF = -__builtin_inf();
+    const bool act = f & F_ACT;
+    if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+        double um = wave_shr1(r.cm), us = wave_shr1(r.cs), uo = 0.0;
+        if (DIR) uo = wave_shr1(r.co);
+        if (lane == 0) { um = xch[r.par][wprev][0]; us = xch[r.par][wprev][1]; if (DIR) uo = xch[r.par][wprev][2]; }
+        // a lane can have served row i - P one step earlier: gate the left / diagonal inputs explicitly
+        const double L = (f & F_RL) ? r.cm : 0.0;
+        const double D = (f & F_RD) ? r.upm : 0.0;
+        const double po = (f & F_RD) ? r.upo : 0.0;
+        r.upm = um;
+        if (DIR) r.upo = uo;
+        const bool top = f & F_TOP;
+        const double ume = top ? NINF : um, use = top ? NINF : us;
+        const double eo = DIR == 0 ? o : uo;
+        const double cSTAY = ume + eo + lst;
+        const double cEXT = use + eo + lex;
+        const double cINS = ume + lin;
+        const double cSKIP = L + lsk;
+        const double cMATCH = DIR == 0 ? D + o : D + po;
+        const double cIGN = D + lin;
+        double ns = top ? -BIG : 0.0;
+        ns = fmax(ns, cSTAY);
+        ns = fmax(ns, cEXT);
+        double nm = fmax(0.0, cSKIP);
+        nm = fmax(nm, cMATCH);
+        nm = fmax(nm, cINS);
+        nm = fmax(nm, cIGN);
+        nm = fmax(nm, ns);
+        const bool live = act && !(f & F_INV);
+        r.cm = live ? nm : 0.0;
+        r.cs = live ? ns : 0.0;
+        if (DIR) r.co = live ? o : 0.0;
+    } else {
+        // no cell for this wave on this anti-diagonal: keep the hand-over chain alive
+        r.upm = 0.0; r.upo = 0.0;
+        if (lane == 0) { r.upm = xch[r.par][wprev][0]; if (DIR) r.upo = xch[r.par][wprev][2]; }
+        r.cm = 0.0; r.cs = 0.0; r.co = 0.0;
+    }
+    *dst = make_double2(r.cm, r.cs);
+    if (lane == 63) { xch[r.par ^ 1][wave][0] = r.cm; xch[r.par ^ 1][wave][1] = r.cs; if (DIR) xch[r.par ^ 1][wave][2] = r.co; }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    r.par ^= 1;
+}
 
 template <int DIR>
 __device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, double (*xch)[16][4]) {
     const int P = J.P, slot = threadIdx.x, lane = slot & 63, wave = slot >> 6, NW = P >> 6;
     const int wprev = (wave + NW - 1) % NW;
     const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
-    const double* __restrict__ em = b.em + J.mat_off[DIR];
-    const unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR];
-    double2* __restrict__ rec = b.rec + J.mat_off[DIR];
-    const int64_t S = J.S;
-    const double NINF = -__builtin_inf();
-    double cm = 0.0, cs = 0.0, co = 0.0;   // this lane's latest main / stay / emission (0 when it had no cell)
-    double upm = 0.0, upo = 0.0;           // what the upper neighbour handed over one step ago
-    int par = 0;
+    const double* __restrict__ em = b.em + J.mat_off[DIR] + slot;
+    const unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR] + slot;
+    double2* __restrict__ rec = b.rec + J.mat_off[DIR] + slot;
+    double2* __restrict__ dummy = b.dummy + (size_t)blockIdx.x * 1024 + slot;
+    const int64_t S = J.S, SL = S - 1;
+    RecurState<DIR> r;
     if (lane == 63) { xch[0][wave][0] = 0.0; xch[0][wave][1] = 0.0; xch[0][wave][2] = 0.0; }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    double e_cur[PF], e_nxt[PF];
-    unsigned f_cur[PF], f_nxt[PF];
-#pragma unroll
-    for (int u = 0; u < PF; u++) {
-        const int64_t s = 2 + u;
-        e_cur[u] = s < S ? em[s * P + slot] : 0.0;
-        f_cur[u] = s < S ? flg[s * P + slot] : 0u;
+    double eA[PF], eB[PF];
+    unsigned fA[PF], fB[PF];
+#define PS_LOAD(E, F, s0)                                                   \
+    _Pragma("unroll") for (int u = 0; u < PF; u++) {                        \
+        const int64_t sc = min((int64_t)(s0) + u, SL) * P;                  \
+        E[u] = em[sc];                                                      \
+        F[u] = flg[sc];                                                     \
     }
-    for (int64_t s0 = 2; s0 < S; s0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int64_t s = s0 + PF + u;
-            e_nxt[u] = s < S ? em[s * P + slot] : 0.0;
-            f_nxt[u] = s < S ? flg[s * P + slot] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int64_t s = s0 + u;
-            if (s < S) {  // uniform over the workgroup
-                const unsigned f = f_cur[u];
-                const bool act = f & F_ACT;
-                if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-                    double um = wave_shr1(cm), us = wave_shr1(cs), uo = 0.0;
-                    if (DIR) uo = wave_shr1(co);
-                    if (lane == 0) { um = xch[par][wprev][0]; us = xch[par][wprev][1]; if (DIR) uo = xch[par][wprev][2]; }
-                    // a lane can have served row i - P one step earlier: gate the left / diagonal inputs explicitly
-                    const double L = (f & F_RL) ? cm : 0.0;
-                    const double D = (f & F_RD) ? upm : 0.0;
-                    const double po = (f & F_RD) ? upo : 0.0;
-                    upm = um;
-                    if (DIR) upo = uo;
-                    const bool top = f & F_TOP;
-                    const double ume = top ? NINF : um, use = top ? NINF : us;
-                    const double o = e_cur[u];
-                    const double eo = DIR == 0 ? o : uo;
-                    const double cSTAY = ume + eo + lst;
-                    const double cEXT = use + eo + lex;
-                    const double cINS = ume + lin;
-                    const double cSKIP = L + lsk;
-                    const double cMATCH = DIR == 0 ? D + o : D + po;
-                    const double cIGN = D + lin;
-                    double ns = top ? -BIG : 0.0;
-                    ns = fmax(ns, cSTAY);
-                    ns = fmax(ns, cEXT);
-                    double nm = fmax(0.0, cSKIP);
-                    nm = fmax(nm, cMATCH);
-                    nm = fmax(nm, cINS);
-                    nm = fmax(nm, cIGN);
-                    nm = fmax(nm, ns);
-                    const bool live = act && !(f & F_INV);
-                    cm = live ? nm : 0.0;
-                    cs = live ? ns : 0.0;
-                    if (DIR) co = live ? o : 0.0;
-                    if (act) rec[s * P + slot] = make_double2(cm, cs);
-                } else {
-                    // no cell for this wave on this anti-diagonal: keep the hand-over chain alive
-                    upm = 0.0; upo = 0.0;
-                    if (lane == 0) { upm = xch[par][wprev][0]; if (DIR) upo = xch[par][wprev][2]; }
-                    cm = 0.0; cs = 0.0; co = 0.0;
-                }
-                if (lane == 63) { xch[par ^ 1][wave][0] = cm; xch[par ^ 1][wave][1] = cs; if (DIR) xch[par ^ 1][wave][2] = co; }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                par ^= 1;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PF; u++) { e_cur[u] = e_nxt[u]; f_cur[u] = f_nxt[u]; }
+#define PS_RUN(E, F, s0)                                                    \
+    _Pragma("unroll") for (int u = 0; u < PF; u++) {                        \
+        const int64_t sv = (int64_t)(s0) + u;                               \
+        const unsigned f = sv < S ? F[u] : 0u;                              \
+        double2* dst = (f & F_ACT) ? rec + sv * P : dummy;                  \
+        recur_step<DIR>(r, E[u], f, dst, xch, lane, wave, wprev, lsk, lst, lex, lin); \
     }
+    PS_LOAD(eA, fA, 2)
+    for (int64_t s0 = 2; s0 < S; s0 += 2 * PF) {   // every wave runs the same padded trip count
+        PS_LOAD(eB, fB, s0 + PF)
+        PS_RUN(eA, fA, s0)
+        PS_LOAD(eA, fA, s0 + 2 * PF)
+        PS_RUN(eB, fB, s0 + PF)
+    }
+#undef PS_LOAD
+#undef PS_RUN
 }
 
 __global__ __launch_bounds__(1024) void k_recur(BatchD b, int ndir) {

@@ -14,8 +14,9 @@
 //   k_vit_trace  nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131), one block each;
 //                the uniform deviates are drawn on the host from libc rand() in the reference's
 //                call order.
-// Max-plus values (liks, back-pointers) are bit-exact; forward probabilities use device exp /
-// pow and tree sums, i.e. agree to a few ulp (they only weight the random back-traces).
+// Max-plus values (liks, back-pointers) are bit-exact; forward probabilities use device exp / log
+// (fwd^atten as exp(atten * log fwd)) and tree sums, i.e. agree to a few ulp; they only weight the
+// random back-traces.
 #include "ps_internal.h"
 
 namespace ps {
@@ -65,54 +66,70 @@ __global__ __launch_bounds__(256) void k_vit_obs(const double* __restrict__ obsi
 
 struct Fam { double mx, prev, fsum; int idx; int pad; };
 
+// ordered combination of two family segments (A precedes B): first strict maximum, the largest
+// value ahead of it, and the forward-probability partial sum
+__device__ __forceinline__ Fam fam_join(const Fam& A, const Fam& B) {
+    Fam r;
+    if (B.mx > A.mx) { r.mx = B.mx; r.idx = B.idx; r.prev = A.mx > B.prev ? A.mx : B.prev; }
+    else { r.mx = A.mx; r.idx = A.idx; r.prev = A.prev; }
+    r.fsum = A.fsum + B.fsum;
+    r.pad = 0;
+    return r;
+}
+
+// families: 0..255 (j=1, 4 members), 256..319 (j=2, 16 members), 320..335 (j=3, 64 members);
+// the j=3 families are scanned as 4 quarters (threads 320..383) and joined.
 __global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ obs, int T, double skip, double stay,
                                                     double lskip, double lstay, double l25,
-                                                    short* __restrict__ bp, double* __restrict__ fwd_out,
+                                                    short* __restrict__ bp, double* __restrict__ lfwd_out,
                                                     double* __restrict__ lik_final, int keep_fwd) {
     __shared__ double s_lik[2][NS], s_fwd[2][NS];
     __shared__ Fam s_fam[336];
+    __shared__ Fam s_q[64];
     __shared__ double s_red[16];
     const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
     s_lik[0][c] = 0.0;
     s_fwd[0][c] = 1.0 / NS;
     __syncthreads();
-    double sp[4], lsp[4];
-    sp[1] = 0.25; lsp[1] = l25;
-    for (int j = 2; j <= 3; j++) { sp[j] = sp[j - 1] * 0.25 * skip; lsp[j] = lsp[j - 1] + l25 + lskip; }
+    const double sp1 = 0.25, sp2 = sp1 * 0.25 * skip, sp3 = sp2 * 0.25 * skip;
+    const double lsp1 = l25, lsp2 = lsp1 + l25 + lskip, lsp3 = lsp2 + l25 + lskip;
+    // this thread's slice of the family pass
+    int fj = 0, fg = 0, k0 = 0, kn = 0;
+    if (c < 256) { fj = 1; fg = c; k0 = 0; kn = 4; }
+    else if (c < 320) { fj = 2; fg = c - 256; k0 = 0; kn = 16; }
+    else if (c < 384) { fj = 3; fg = (c - 320) & 15; k0 = ((c - 320) >> 4) * 16; kn = 16; }
+    const int fsh = 10 - 2 * fj;
+    const double fsp = fj == 1 ? sp1 : fj == 2 ? sp2 : sp3;
     int cur = 0;
     for (int t = 0; t < T; t++) {
         const double* pl = s_lik[cur];
         const double* pf = s_fwd[cur];
-        // ---- family pass: families 0..255 (j=1, 4 members), 256..319 (j=2, 16), 320..335 (j=3, 64)
-        if (c < 336) {
-            int j, g;
-            if (c < 256) { j = 1; g = c; } else if (c < 320) { j = 2; g = c - 256; } else { j = 3; g = c - 320; }
-            const int cnt = 1 << (2 * j), sh = 10 - 2 * j;
-            double mx = -BIG * 10, prev = -BIG * 10, fs = 0.0;
-            int idx = -1;
-            for (int k = 0; k < cnt; k++) {
-                const int q = g + (k << sh);
+        const double o = obs[(size_t)t * NS + c];
+        if (c < 384) {
+            Fam f;
+            f.mx = -BIG * 10; f.prev = -BIG * 10; f.fsum = 0.0; f.idx = -1; f.pad = 0;
+            for (int k = k0; k < k0 + kn; k++) {
+                const int q = fg + (k << fsh);
                 const double x = pl[q];
-                fs += sp[j] * pf[q];
-                if (idx < 0 || x > mx) { mx = x; idx = q; }   // first strict maximum
+                f.fsum += fsp * pf[q];
+                if (f.idx < 0) { f.mx = x; f.idx = q; }
+                else if (x > f.mx) { f.prev = f.mx; f.mx = x; f.idx = q; }   // all earlier values are <= the old maximum
             }
-            for (int k = 0; k < cnt; k++) {                     // largest value ahead of it
-                const int q = g + (k << sh);
-                if (q == idx) break;
-                const double x = pl[q];
-                if (x > prev) prev = x;
-            }
-            s_fam[c].mx = mx; s_fam[c].prev = prev; s_fam[c].fsum = fs; s_fam[c].idx = idx;
+            if (c < 320) s_fam[c] = f; else s_q[c - 320] = f;
+        }
+        __syncthreads();
+        if (c < 16) {
+            Fam f = fam_join(fam_join(s_q[c], s_q[16 + c]), fam_join(s_q[32 + c], s_q[48 + c]));
+            s_fam[320 + c] = f;
         }
         __syncthreads();
         // ---- destination pass
-        const double o = obs[(size_t)t * NS + c];
         double best = -BIG; int bq = -1; double fsum = 0.0;
 #pragma unroll
         for (int j = 1; j <= 3; j++) {
             const int g = c >> (2 * j);
             const Fam& f = s_fam[(j == 1 ? 0 : j == 2 ? 256 : 320) + g];
-            const double a = o + lsp[j];
+            const double a = o + (j == 1 ? lsp1 : j == 2 ? lsp2 : lsp3);
             const double m = a + f.mx;
             fsum += f.fsum;
             if (f.prev > -BIG * 5 && a + f.prev == m) {
@@ -143,68 +160,79 @@ __global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ o
         s_lik[cur ^ 1][c] = best;
         s_fwd[cur ^ 1][c] = nf;
         bp[(size_t)t * NS + c] = (short)bq;
-        if (keep_fwd) fwd_out[(size_t)t * NS + c] = nf;
+        if (keep_fwd) lfwd_out[(size_t)t * NS + c] = log(nf);   // the back-traces need fwd^atten = exp(atten * log fwd)
         __syncthreads();
         cur ^= 1;
     }
     lik_final[c] = s_lik[cur][c];
 }
 
-// nkeep stochastic back-traces; grid nkeep, block 1024.  path[k][i] for i = T-1 .. 0
-__global__ __launch_bounds__(1024) void k_vit_trace(const double* __restrict__ fwd, const double* __restrict__ Tm, int T,
-                                                    int start, const double* __restrict__ atten, const double* __restrict__ rnd,
-                                                    short* __restrict__ path) {
-    __shared__ double s_scan[16];
-    __shared__ int s_pick;
-    const int k = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+// T[cur][p] of buildT (cpp/Viterbi.cpp:134-168) in closed form: predecessor p is reached by a j-base
+// advance iff its low 10-2j bits equal cur's high bits; contributions add in j order; the diagonal is
+// overwritten with the stay probability.
+__device__ __forceinline__ double trans_weight(int cur, int p, double skip, double stay) {
+    double t = 0.0, sp = 0.25;
+#pragma unroll
+    for (int j = 1; j <= 4; j++) {
+        if ((p & ((1 << (10 - 2 * j)) - 1)) == (cur >> (2 * j))) t += sp;
+        sp = sp * 0.25 * skip;
+    }
+    if (p == cur) t = stay;
+    return t;
+}
+
+// nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131): one wave per path, lane l owns the
+// 16 states 16l .. 16l+15 (so the running sum is in state order); the step's log-forward row is staged
+// in LDS one step ahead.  grid nkeep, block 64.
+__global__ __launch_bounds__(64) void k_vit_trace(const double* __restrict__ lfwd, int T, int start, double skip, double stay,
+                                                  const double* __restrict__ atten, const double* __restrict__ rnd,
+                                                  short* __restrict__ path) {
+    const int k = blockIdx.x, l = threadIdx.x;
     const double at = atten[k];
     int cur = start;
+    double lf[16], nx[16];
+    {
+        const double* row = lfwd + (size_t)(T - 1) * NS + 16 * l;
+#pragma unroll
+        for (int m = 0; m < 16; m++) lf[m] = row[m];
+    }
     for (int i = T - 1; i >= 0; i--) {
-        if (c == 0) { path[(size_t)k * T + i] = (short)cur; s_pick = NS - 1; }
-        // scores[i+1]->randbp(cur, ...): step index i+1 in the reference == stored step i here
-        const double tv = Tm[(size_t)cur * NS + c];
-        double p = tv == 0.0 ? 0.0 : tv * pow(fwd[(size_t)i * NS + c], at);
-        // total
-        double s = p;
-        for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-        __syncthreads();
-        if (lane == 0) s_scan[wave] = s;
-        __syncthreads();
+        if (l == 0) path[(size_t)k * T + i] = (short)cur;
+        if (i > 0) {
+            const double* row = lfwd + (size_t)(i - 1) * NS + 16 * l;
+#pragma unroll
+            for (int m = 0; m < 16; m++) nx[m] = row[m];
+        }
+        double pr[16];
         double tot = 0.0;
-        for (int w = 0; w < 16; w++) tot += s_scan[w];
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const double tv = trans_weight(cur, 16 * l + m, skip, stay);
+            const double x = tv == 0.0 ? 0.0 : tv * exp(at * lf[m]);
+            pr[m] = x;
+            tot += x;
+        }
+        for (int off = 32; off; off >>= 1) tot += __shfl_xor(tot, off);
         tot = 1.0 / tot;
-        p *= tot;
-        // inclusive prefix sum over the 1024 states
-        double x = p;
-        for (int off = 1; off < 64; off <<= 1) { const double y = __shfl_up(x, off); if (lane >= off) x += y; }
-        __syncthreads();
-        if (lane == 63) s_scan[wave] = x;
-        __syncthreads();
-        double basev = 0.0;
-        for (int w = 0; w < wave; w++) basev += s_scan[w];
-        x += basev;
+        double run = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) { pr[m] *= tot; run += pr[m]; }
+        // exclusive prefix of the lane totals
+        double x = run;
+        for (int off = 1; off < 64; off <<= 1) { const double y = __shfl_up(x, off); if (l >= off) x += y; }
+        double cs = x - run;
         const double r = rnd[(size_t)k * T + (T - 1 - i)];
-        if (r < x) atomicMin(&s_pick, c);
-        __syncthreads();
-        cur = s_pick;
-        __syncthreads();
+        int pick = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < 16; m++) { cs += pr[m]; if (pick == 0x7fffffff && r < cs) pick = 16 * l + m; }
+        for (int off = 32; off; off >>= 1) pick = min(pick, __shfl_xor(pick, off));
+        cur = pick == 0x7fffffff ? NS - 1 : pick;
+#pragma unroll
+        for (int m = 0; m < 16; m++) lf[m] = nx[m];
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-static std::vector<double> build_T(double skip, double stay) {  // buildT, cpp/Viterbi.cpp:134-168
-    std::vector<double> Tm((size_t)NS * NS, 0.0);
-    for (int c = 0; c < NS; c++) {
-        double sp = 0.25;
-        for (int j = 1; j <= 4; j++) {
-            for (int k = 0; k < (1 << (2 * j)); k++) Tm[(size_t)c * NS + ((c >> (2 * j)) + (k << (10 - 2 * j)))] += sp;
-            sp = sp * 0.25 * skip;
-        }
-    }
-    for (int i = 0; i < NS; i++) Tm[(size_t)i * (NS + 1)] = stay;
-    return Tm;
-}
-
 int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const double* d_model, int nkeep,
                    double skip, double stay, double mmin, double mmax, const double* h_rand,
                    std::vector<std::vector<int>>* paths) {
@@ -242,15 +270,6 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
         paths->push_back(p);
         return PS_OK;
     }
-    // transition matrix for the back-steps, cached per (skip, stay)
-    static double t_skip = -1, t_stay = -1;
-    PS_TRY(rt->buf("vit_T").ensure((size_t)NS * NS * sizeof(double)));
-    if (t_skip != skip || t_stay != stay) {
-        std::vector<double> Tm = build_T(skip, stay);
-        PS_HIP(hipMemcpyAsync(rt->buf("vit_T").p, Tm.data(), Tm.size() * sizeof(double), hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipStreamSynchronize(rt->stream));
-        t_skip = skip; t_stay = stay;
-    }
     std::vector<double> att(nkeep);
     for (int k = 0; k < nkeep; k++) att[k] = mmin + (mmax - mmin) * k / (double)nkeep;
     PS_TRY(rt->buf("vit_att").ensure(nkeep * sizeof(double)));
@@ -258,7 +277,7 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
     PS_TRY(rt->buf("vit_path").ensure((size_t)nkeep * T * sizeof(short)));
     PS_HIP(hipMemcpyAsync(rt->buf("vit_att").p, att.data(), nkeep * sizeof(double), hipMemcpyHostToDevice, rt->stream));
     PS_HIP(hipMemcpyAsync(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * T * sizeof(double), hipMemcpyHostToDevice, rt->stream));
-    hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(1024), 0, rt->stream, d_fwd, rt->buf("vit_T").as<double>(), T, start,
+    hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(64), 0, rt->stream, d_fwd, T, start, skip, stay,
                        rt->buf("vit_att").as<double>(), rt->buf("vit_rnd").as<double>(), rt->buf("vit_path").as<short>());
     PS_HIP(hipGetLastError());
     prof_end(rt, "viterbi", (double)T * NS * (8.0 * E + 8 + 2 + 8 + 8.0 * nkeep));
