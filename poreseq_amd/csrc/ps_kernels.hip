@@ -500,26 +500,29 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
 // ------------------------------------------------------------------------------------------------
 // backtrace (cpp/Alignment.cpp:516-624): one wave per job, 16x16 tiles staged in LDS
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_backtrace(BatchD b) {
+constexpr int BT = 32;   // tile edge of the backtrace
+
+__global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
     const JobD& J = b.jobs[blockIdx.x];
     if (b.out[blockIdx.x].inert) return;  // stripe_width == 0: the event is left untouched
     const JobOut O = b.out[blockIdx.x];
-    const int lane = threadIdx.x, P = J.P, n0 = J.n0;
+    const int tid = threadIdx.x, P = J.P, n0 = J.n0;
     double* __restrict__ ra = J.ra;
     double* __restrict__ rl = J.rl;
-    for (int t = lane; t < n0; t += 64) { ra[t] = 0.0; rl[t] = 0.0; }
+    for (int t = tid; t < n0; t += 256) { ra[t] = 0.0; rl[t] = 0.0; }
     __syncthreads();
     const double2* __restrict__ rec = b.rec + J.mat_off[0];
     const unsigned short* __restrict__ flg = b.flg + J.mat_off[0];
-    __shared__ double t_main[16][17], t_stay[16][17];
-    __shared__ unsigned short t_step[16][17];
+    __shared__ double t_main[BT][BT + 1], t_stay[BT][BT + 1];
+    __shared__ unsigned short t_step[BT][BT + 2];
+    __shared__ int s_state[4];
     int i = O.bi, j = O.bj, arr = 0;
     bool done = (i <= 0);
     while (!done) {
         const int ti = i, tj = j;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int idx = lane + 64 * q, a = idx >> 4, c = idx & 15;
+        for (int q = 0; q < BT * BT / 256; q++) {
+            const int idx = tid + 256 * q, a = idx / BT, c = idx % BT;
             const int r = ti - a, col = tj - c;
             double m = 0.0, s = 0.0; unsigned short st = 0;
             if (r >= 1 && col >= 1) {
@@ -530,11 +533,11 @@ __global__ __launch_bounds__(64) void k_backtrace(BatchD b) {
             t_main[a][c] = m; t_stay[a][c] = s; t_step[a][c] = st;
         }
         __syncthreads();
-        if (lane == 0) {
+        if (tid == 0) {
             while (true) {
                 const int a = ti - i, c = tj - j;
                 if (i <= 0) { done = true; break; }
-                if (a > 15 || c > 15) break;  // next tile
+                if (a >= BT || c >= BT) break;  // next tile
                 const unsigned stp = t_step[a][c];
                 const unsigned st = arr ? (stp >> 8) : (stp & 255u);
                 const double sc = arr ? t_stay[a][c] : t_main[a][c];
@@ -550,9 +553,10 @@ __global__ __launch_bounds__(64) void k_backtrace(BatchD b) {
                 else if (st == M_EXTEND) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
                 else { done = true; break; }
             }
+            s_state[0] = i; s_state[1] = j; s_state[2] = arr; s_state[3] = done ? 1 : 0;
         }
-        i = __shfl(i, 0); j = __shfl(j, 0); arr = __shfl(arr, 0);
-        done = __shfl((int)done, 0) != 0;
+        __syncthreads();
+        i = s_state[0]; j = s_state[1]; arr = s_state[2]; done = s_state[3] != 0;
         __syncthreads();
     }
 }
@@ -807,7 +811,7 @@ int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int
 
 int launch_backtrace(Runtime* rt, const BatchD& b, int) {
     if (!b.njobs) return PS_OK;
-    hipLaunchKernelGGL(k_backtrace, dim3(b.njobs), dim3(64), 0, rt->stream, b);
+    hipLaunchKernelGGL(k_backtrace, dim3(b.njobs), dim3(256), 0, rt->stream, b);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }

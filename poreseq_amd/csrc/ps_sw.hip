@@ -16,7 +16,7 @@
 namespace ps {
 
 constexpr int TC = 256;
-constexpr int TSTEPS = TC + 63;
+constexpr int TSTEPS = ((TC + 63 + 3) / 4) * 4;   // steps per tile, padded to whole 4-step store groups
 
 struct SwPair {
     int n1, n2, ntr, ntc;
@@ -35,7 +35,7 @@ __device__ __forceinline__ int shr1_i(int v) {
 
 __global__ __launch_bounds__(64) void k_sw_tiles(const SwPair* pairs, const char* chars, unsigned char* steps,
                                                  int* hrow, int* hcol, int4* tiles, int d) {
-    const SwPair& p = pairs[blockIdx.y];
+    const SwPair p = pairs[blockIdx.y];   // by value: through a reference hipcc re-reads n2 from memory on every step
     const int rmin = max(0, d - (p.ntc - 1)), rmax = min(p.ntr - 1, d);
     const int r = rmin + blockIdx.x;
     if (r > rmax) return;
@@ -60,29 +60,51 @@ __global__ __launch_bounds__(64) void k_sw_tiles(const SwPair* pairs, const char
     int prevup = shr1_i(left);                     // H(i-1, j0)
     if (l == 0) prevup = s_top[0];
     int best = 0, bestj = 0;
-    unsigned char* st = steps + p.steps_off + (int64_t)(r * p.ntc + c) * TSTEPS * 64;
-    for (int t = 0; t < TSTEPS; t++) {
-        const int jj = t - l;
-        int up = shr1_i(h);
-        if (l == 0) up = s_top[min(t + 1, TC)];
-        const int diag = prevup;
-        prevup = up;
-        unsigned char code = 0;
-        if (jj >= 0 && jj < TC && rowok && j0 + 1 + jj <= p.n2) {
-            int score = 0, step = 0;
-            int s = h - 8;                       // from the left: H(i, j-1)
-            if (s > score) { score = s; step = 1; }
-            s = up - 8;                          // from above: H(i-1, j)
-            if (s > score) { score = s; step = 2; }
-            const bool eq = c1 == s_c2[jj];
-            s = diag + (eq ? 5 : -4);
-            if (s >= score) { score = s; step = 3; }
-            h = score;
-            code = (unsigned char)(step | (score > 0 ? 4 : 0) | (eq ? 8 : 0));
-            if (score > best) { best = score; bestj = j0 + 1 + jj; }
-            if (l == 63) s_bot[jj] = score;
+    // step codes: 4 consecutive steps of a lane are packed into one 32-bit store, [t/4][lane][t%4]
+    unsigned* st = (unsigned*)(steps + p.steps_off + (int64_t)(r * p.ntc + c) * TSTEPS * 64);
+    for (int t0 = 0; t0 < TSTEPS; t0 += 4) {
+        // LDS operands of the next four steps, issued together (one lgkmcnt wait per four steps)
+        int tops[4];
+        char ch[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + u;
+            tops[u] = s_top[min(t + 1, TC)];
+            ch[u] = s_c2[min(max(t - l, 0), TC - 1)];
         }
-        st[t * 64 + l] = code;
+        unsigned packed = 0;
+        int bots[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + u;
+            const int jj = t - l;
+            int up = shr1_i(h);
+            if (l == 0) up = tops[u];
+            const int diag = prevup;
+            prevup = up;
+            unsigned code = 0;
+            bots[u] = 0;
+            if (t < TSTEPS && jj >= 0 && jj < TC && rowok && j0 + 1 + jj <= p.n2) {
+                int score = 0, step = 0;
+                int s = h - 8;                       // from the left: H(i, j-1)
+                if (s > score) { score = s; step = 1; }
+                s = up - 8;                          // from above: H(i-1, j)
+                if (s > score) { score = s; step = 2; }
+                const bool eq = c1 == ch[u];
+                s = diag + (eq ? 5 : -4);
+                if (s >= score) { score = s; step = 3; }
+                h = score;
+                code = (unsigned)(step | (score > 0 ? 4 : 0) | (eq ? 8 : 0));
+                if (score > best) { best = score; bestj = j0 + 1 + jj; }
+                bots[u] = score;
+            }
+            packed |= code << (8 * u);
+        }
+        if (t0 < TSTEPS) st[(t0 >> 2) * 64 + l] = packed;
+        if (l == 63) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int jj = t0 + u - 63; if (jj >= 0 && jj < TC) s_bot[jj] = bots[u]; }
+        }
     }
     if (rowok) hc[i] = h;
     // tile maximum: largest score, then smallest column, then smallest row (column-major first hit)
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(64) void k_sw_tiles(const SwPair* pairs, const char
 }
 
 __global__ __launch_bounds__(64) void k_sw_best(const SwPair* pairs, const int4* tiles, int* res) {
-    const SwPair& p = pairs[blockIdx.x];
+    const SwPair p = pairs[blockIdx.x];
     const int l = threadIdx.x, nt = p.ntr * p.ntc;
     int bs = 0, bi = 0, bj = 0x7fffffff;
     for (int k = l; k < nt; k += 64) {
@@ -117,7 +139,7 @@ __global__ __launch_bounds__(64) void k_sw_best(const SwPair* pairs, const int4*
 }
 
 __global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const unsigned char* steps, int* out, int* res) {
-    const SwPair& p = pairs[blockIdx.x];
+    const SwPair p = pairs[blockIdx.x];
     const int l = threadIdx.x;
     __shared__ unsigned char s_t[TSTEPS * 64];
     int* o = res + p.res_off;
@@ -138,7 +160,8 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const unsi
                 if (!(i > 0 && j > 0)) { done = true; break; }
                 const int ll = i - i0 - 1, jj = j - j0 - 1;
                 if (ll < 0 || jj < 0) break;  // left this tile
-                const unsigned code = s_t[(jj + ll) * 64 + ll];
+                const int tt = jj + ll;
+                const unsigned code = s_t[((tt >> 2) * 64 + ll) * 4 + (tt & 3)];
                 if (!(code & 4)) { done = true; break; }   // score <= 0
                 const unsigned stp = code & 3;
                 if (stp == 1) { oi[np] = 0; oj[np] = j; np++; j--; }

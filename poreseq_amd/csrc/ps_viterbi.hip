@@ -8,9 +8,9 @@
 //                of a destination state depend only on its low bits, so the per-family maximum,
 //                its first index and the forward-probability sum are computed once per family
 //                (336 families) instead of once per state.  The first-strict-maximum rule of the
-//                reference is kept exactly: a family remembers the largest value that precedes its
-//                first maximum, and a destination state falls back to the plain ordered scan in the
-//                (sub-ulp) case where that value would round to the same sum.
+//                reference is kept exactly: a family also remembers its second-largest value, and a
+//                destination state falls back to the plain ordered scan in the (sub-ulp) case where
+//                that value would round to the same sum as the maximum.
 //   k_vit_trace  nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131), one block each;
 //                the uniform deviates are drawn on the host from libc rand() in the reference's
 //                call order.
@@ -34,7 +34,7 @@ constexpr int VMAXE = 64;  // events handled per position without spilling to th
 
 // obsin[t][e][4] = {level mean, sd mean, log(sd mean), present}; obs[t][1024]
 __global__ __launch_bounds__(256) void k_vit_obs(const double* __restrict__ obsin, const double* __restrict__ model,
-                                                 int E, double log2pi, double* __restrict__ obs) {
+                                                 int E, double log2pi, double* __restrict__ obs, double* __restrict__ eobs) {
     const int t = blockIdx.x;
     const double* in = obsin + (size_t)t * E * 4;
     for (int st = threadIdx.x; st < NS; st += 256) {
@@ -61,69 +61,122 @@ __global__ __launch_bounds__(256) void k_vit_obs(const double* __restrict__ obsi
             r = nl == 1 ? v[0] : 0.0;
         }
         obs[(size_t)t * NS + st] = r;
+        eobs[(size_t)t * NS + st] = exp(r);   // V_LIK multiplies the forward sum by exp(obs), cpp/Viterbi.cpp:91
     }
 }
 
-struct Fam { double mx, prev, fsum; int idx; int pad; };
+// workgroup barrier that waits for LDS traffic only: __syncthreads() would also drain vmcnt(0), i.e.
+// expose a full HBM round trip for the prefetched inputs and the streaming stores on every step
+#define PS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// ordered combination of two family segments (A precedes B): first strict maximum, the largest
-// value ahead of it, and the forward-probability partial sum
+// Statistics of one predecessor family (the 4 / 16 / 64 states a destination can come from with a
+// 1 / 2 / 3-base advance): maximum of the previous Viterbi scores, the SMALLEST state index among the
+// maxima (= the first one the reference's ordered scan meets, since it scans in ascending state order),
+// the largest value strictly below the maximum, and the sum of the previous forward probabilities.
+// All four combine commutatively, and the families nest (state mod 256 -> mod 64 -> mod 16).
+struct Fam { double mx, second, psum; int idx; int pad; };
+
 __device__ __forceinline__ Fam fam_join(const Fam& A, const Fam& B) {
     Fam r;
-    if (B.mx > A.mx) { r.mx = B.mx; r.idx = B.idx; r.prev = A.mx > B.prev ? A.mx : B.prev; }
-    else { r.mx = A.mx; r.idx = A.idx; r.prev = A.prev; }
-    r.fsum = A.fsum + B.fsum;
+    const double s2 = A.second > B.second ? A.second : B.second;
+    if (B.mx > A.mx) { r.mx = B.mx; r.idx = B.idx; r.second = A.mx > s2 ? A.mx : s2; }
+    else if (B.mx < A.mx) { r.mx = A.mx; r.idx = A.idx; r.second = B.mx > s2 ? B.mx : s2; }
+    else { r.mx = A.mx; r.idx = A.idx < B.idx ? A.idx : B.idx; r.second = s2; }
+    r.psum = A.psum + B.psum;
     r.pad = 0;
     return r;
 }
+// DPP row shift: lane i receives lane i + N of its 16-lane row (zero past the row end)
+template <int N>
+__device__ __forceinline__ double row_shl(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ Fam fam_shl(const Fam& f) {
+    Fam o;
+    o.mx = row_shl<N>(f.mx); o.second = row_shl<N>(f.second); o.psum = row_shl<N>(f.psum);
+    o.idx = __builtin_amdgcn_update_dpp(0, f.idx, 0x100 + N, 0xf, 0xf, true); o.pad = 0;
+    return o;
+}
+// sum over the 64 lanes of a wave: DPP inside the rows, then the four row sums through SGPRs
+__device__ __forceinline__ double wave_sum(double v) {
+    v += row_shl<1>(v); v += row_shl<2>(v); v += row_shl<4>(v); v += row_shl<8>(v);
+    auto lane_d = [&](int l) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+        return __hiloint2double(hi, lo);
+    };
+    return (lane_d(0) + lane_d(16)) + (lane_d(32) + lane_d(48));
+}
 
-// families: 0..255 (j=1, 4 members), 256..319 (j=2, 16 members), 320..335 (j=3, 64 members);
-// the j=3 families are scanned as 4 quarters (threads 320..383) and joined.
-__global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ obs, int T, double skip, double stay,
+// families: s_fam[0..255] (1-base advance, key = state mod 256), [256..319] (2-base, mod 64), [320..335] (3-base, mod 16)
+//
+// Forward probabilities: the reference renormalises the 1024-vector after every step
+// (normvec, cpp/Viterbi.cpp:101).  Only ratios within one step's vector are ever used (randbp
+// renormalises its own products), so here each step is rescaled by an exact power of two taken from
+// the PREVIOUS step's total: the vector stays in range, no rounding is added, and the reduce -> divide
+// chain leaves the per-step critical path.
+__global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ obs, const double* __restrict__ eobs, int T, double skip, double stay,
                                                     double lskip, double lstay, double l25,
                                                     short* __restrict__ bp, double* __restrict__ lfwd_out,
                                                     double* __restrict__ lik_final, int keep_fwd) {
     __shared__ double s_lik[2][NS], s_fwd[2][NS];
     __shared__ Fam s_fam[336];
-    __shared__ Fam s_q[64];
-    __shared__ double s_red[16];
+    __shared__ double s_red[2][16];
     const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
     s_lik[0][c] = 0.0;
     s_fwd[0][c] = 1.0 / NS;
+    if (c < 32) s_red[c >> 4][c & 15] = 1.0 / 16;   // "previous total" of the initial vector: 1
     __syncthreads();
     const double sp1 = 0.25, sp2 = sp1 * 0.25 * skip, sp3 = sp2 * 0.25 * skip;
     const double lsp1 = l25, lsp2 = lsp1 + l25 + lskip, lsp3 = lsp2 + l25 + lskip;
-    // this thread's slice of the family pass
-    int fj = 0, fg = 0, k0 = 0, kn = 0;
-    if (c < 256) { fj = 1; fg = c; k0 = 0; kn = 4; }
-    else if (c < 320) { fj = 2; fg = c - 256; k0 = 0; kn = 16; }
-    else if (c < 384) { fj = 3; fg = (c - 320) & 15; k0 = ((c - 320) >> 4) * 16; kn = 16; }
-    const int fsh = 10 - 2 * fj;
-    const double fsp = fj == 1 ? sp1 : fj == 2 ? sp2 : sp3;
+    // family pass layout for threads u < 256: u = 16 g3 + 4 m2 + m  ->  g2 = g3 + 16 m2, g1 = g2 + 64 m
+    const int fg3 = c >> 4, fm2 = (c >> 2) & 3, fm = c & 3;
+    const int fg2 = fg3 + 16 * fm2, fg1 = fg2 + 64 * fm;
     int cur = 0;
-    for (int t = 0; t < T; t++) {
+    constexpr int VPF = 4;   // steps of obs / exp(obs) kept in flight in registers
+    double oA[VPF], eA[VPF], oB[VPF], eB[VPF];
+    const int TL = T - 1;
+#define VIT_LOAD(O, E, t0)                                             \
+    _Pragma("unroll") for (int u = 0; u < VPF; u++) {                   \
+        const size_t at = (size_t)min((t0) + u, TL) * NS + c;           \
+        O[u] = obs[at]; E[u] = eobs[at];                                \
+    }
+#define VIT_RUN(O, E, t0)                                               \
+    _Pragma("unroll") for (int u = 0; u < VPF; u++) {                   \
+        if ((t0) + u < T) vit_one((t0) + u, O[u], E[u]);                \
+    }
+    auto vit_one = [&](const int t, const double o, const double eo) {
         const double* pl = s_lik[cur];
         const double* pf = s_fwd[cur];
-        const double o = obs[(size_t)t * NS + c];
-        if (c < 384) {
+        // power-of-two rescale from the previous step's total (all lanes read the same 16 partials)
+        double ptot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) ptot += s_red[cur][w];
+        int ex;
+        frexp(ptot, &ex);
+        const double scale = ldexp(1.0, -ex);
+        if (c < 256) {
             Fam f;
-            f.mx = -BIG * 10; f.prev = -BIG * 10; f.fsum = 0.0; f.idx = -1; f.pad = 0;
-            for (int k = k0; k < k0 + kn; k++) {
-                const int q = fg + (k << fsh);
-                const double x = pl[q];
-                f.fsum += fsp * pf[q];
-                if (f.idx < 0) { f.mx = x; f.idx = q; }
-                else if (x > f.mx) { f.prev = f.mx; f.mx = x; f.idx = q; }   // all earlier values are <= the old maximum
+            f.mx = pl[fg1]; f.idx = fg1; f.second = -BIG * 10; f.psum = pf[fg1]; f.pad = 0;
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                Fam g;
+                const int q = fg1 + (k << 8);
+                g.mx = pl[q]; g.idx = q; g.second = -BIG * 10; g.psum = pf[q]; g.pad = 0;
+                f = fam_join(f, g);
             }
-            if (c < 320) s_fam[c] = f; else s_q[c - 320] = f;
+            s_fam[fg1] = f;
+            f = fam_join(f, fam_shl<1>(f));
+            f = fam_join(f, fam_shl<2>(f));
+            if (fm == 0) s_fam[256 + fg2] = f;
+            f = fam_join(f, fam_shl<4>(f));
+            f = fam_join(f, fam_shl<8>(f));
+            if ((c & 15) == 0) s_fam[320 + fg3] = f;
         }
-        __syncthreads();
-        if (c < 16) {
-            Fam f = fam_join(fam_join(s_q[c], s_q[16 + c]), fam_join(s_q[32 + c], s_q[48 + c]));
-            s_fam[320 + c] = f;
-        }
-        __syncthreads();
-        // ---- destination pass
+        PS_LDS_BARRIER();
         double best = -BIG; int bq = -1; double fsum = 0.0;
 #pragma unroll
         for (int j = 1; j <= 3; j++) {
@@ -131,9 +184,9 @@ __global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ o
             const Fam& f = s_fam[(j == 1 ? 0 : j == 2 ? 256 : 320) + g];
             const double a = o + (j == 1 ? lsp1 : j == 2 ? lsp2 : lsp3);
             const double m = a + f.mx;
-            fsum += f.fsum;
-            if (f.prev > -BIG * 5 && a + f.prev == m) {
-                // an earlier, smaller member rounds to the same sum: ordered scan (reference order)
+            fsum += (j == 1 ? sp1 : j == 2 ? sp2 : sp3) * f.psum;
+            if (f.second > -BIG * 5 && a + f.second == m) {
+                // a smaller member rounds to the same sum and may come first: ordered scan (reference order)
                 const int cnt = 1 << (2 * j), sh = 10 - 2 * j;
                 for (int k = 0; k < cnt; k++) {
                     const int q = g + (k << sh);
@@ -147,23 +200,25 @@ __global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ o
             if (l > best) { best = l; bq = c; }
             fsum += stay * pf[c];
         }
-        fsum *= exp(o);
-        // ---- normalise forward probabilities (wave tree + 16-entry tree)
-        double ssum = fsum;
-        for (int off = 32; off; off >>= 1) ssum += __shfl_xor(ssum, off);
-        if (lane == 0) s_red[wave] = ssum;
-        __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < 16; w++) tot += s_red[w];
-        tot = 1.0 / tot;
-        const double nf = fsum * tot;
+        const double nf = fsum * eo * scale;
+        const double wsum = wave_sum(nf);
+        if (lane == 0) s_red[cur ^ 1][wave] = wsum;
         s_lik[cur ^ 1][c] = best;
         s_fwd[cur ^ 1][c] = nf;
         bp[(size_t)t * NS + c] = (short)bq;
-        if (keep_fwd) lfwd_out[(size_t)t * NS + c] = log(nf);   // the back-traces need fwd^atten = exp(atten * log fwd)
-        __syncthreads();
+        if (keep_fwd) lfwd_out[(size_t)t * NS + c] = nf;
+        PS_LDS_BARRIER();
         cur ^= 1;
+    };
+    VIT_LOAD(oA, eA, 0)
+    for (int t0 = 0; t0 < T; t0 += 2 * VPF) {
+        VIT_LOAD(oB, eB, t0 + VPF)
+        VIT_RUN(oA, eA, t0)
+        VIT_LOAD(oA, eA, t0 + 2 * VPF)
+        VIT_RUN(oB, eB, t0 + VPF)
     }
+#undef VIT_LOAD
+#undef VIT_RUN
     lik_final[c] = s_lik[cur][c];
 }
 
@@ -181,54 +236,65 @@ __device__ __forceinline__ double trans_weight(int cur, int p, double skip, doub
     return t;
 }
 
-// nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131): one wave per path, lane l owns the
-// 16 states 16l .. 16l+15 (so the running sum is in state order); the step's log-forward row is staged
-// in LDS one step ahead.  grid nkeep, block 64.
-__global__ __launch_bounds__(64) void k_vit_trace(const double* __restrict__ lfwd, int T, int start, double skip, double stay,
+// fwd -> log(fwd) in place, chip-wide: the back-traces need fwd^atten = exp(atten * log fwd)
+__global__ void k_vit_log(double* __restrict__ v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = log(v[i]);
+}
+
+// nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131): one 256-thread block per path,
+// thread t owns states 4t .. 4t+3 (so running sums are in state order).  grid nkeep.
+__global__ __launch_bounds__(256) void k_vit_trace(const double* __restrict__ lfwd, int T, int start, double skip, double stay,
                                                   const double* __restrict__ atten, const double* __restrict__ rnd,
                                                   short* __restrict__ path) {
-    const int k = blockIdx.x, l = threadIdx.x;
+    __shared__ double s_tot[2][4], s_run[2][4];
+    __shared__ int s_pick[2];
+    const int k = blockIdx.x, t = threadIdx.x, l = t & 63, w = t >> 6;
     const double at = atten[k];
     int cur = start;
-    double lf[16], nx[16];
-    {
-        const double* row = lfwd + (size_t)(T - 1) * NS + 16 * l;
-#pragma unroll
-        for (int m = 0; m < 16; m++) lf[m] = row[m];
-    }
+    double4 lf = *(const double4*)(lfwd + (size_t)(T - 1) * NS + 4 * t);
+    double rcur = rnd[(size_t)k * T];
+    if (t < 2) s_pick[t] = 0x7fffffff;
+    PS_LDS_BARRIER();
     for (int i = T - 1; i >= 0; i--) {
-        if (l == 0) path[(size_t)k * T + i] = (short)cur;
-        if (i > 0) {
-            const double* row = lfwd + (size_t)(i - 1) * NS + 16 * l;
-#pragma unroll
-            for (int m = 0; m < 16; m++) nx[m] = row[m];
-        }
-        double pr[16];
+        const int par = i & 1;
+        if (t == 0) path[(size_t)k * T + i] = (short)cur;
+        double4 nx = lf;
+        double rnx = rcur;
+        if (i > 0) { nx = *(const double4*)(lfwd + (size_t)(i - 1) * NS + 4 * t); rnx = rnd[(size_t)k * T + (T - i)]; }
+        double pr[4];
+        const double lv[4] = {lf.x, lf.y, lf.z, lf.w};
         double tot = 0.0;
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const double tv = trans_weight(cur, 16 * l + m, skip, stay);
-            const double x = tv == 0.0 ? 0.0 : tv * exp(at * lf[m]);
-            pr[m] = x;
-            tot += x;
+        for (int m = 0; m < 4; m++) {
+            const double tv = trans_weight(cur, 4 * t + m, skip, stay);
+            pr[m] = tv == 0.0 ? 0.0 : tv * exp(at * lv[m]);
+            tot += pr[m];
         }
         for (int off = 32; off; off >>= 1) tot += __shfl_xor(tot, off);
-        tot = 1.0 / tot;
+        if (l == 0) s_tot[par][w] = tot;
+        PS_LDS_BARRIER();
+        tot = 1.0 / (s_tot[par][0] + s_tot[par][1] + s_tot[par][2] + s_tot[par][3]);
         double run = 0.0;
 #pragma unroll
-        for (int m = 0; m < 16; m++) { pr[m] *= tot; run += pr[m]; }
-        // exclusive prefix of the lane totals
+        for (int m = 0; m < 4; m++) { pr[m] *= tot; run += pr[m]; }
         double x = run;
         for (int off = 1; off < 64; off <<= 1) { const double y = __shfl_up(x, off); if (l >= off) x += y; }
+        if (l == 63) s_run[par][w] = x;
+        if (t == 0) s_pick[par ^ 1] = 0x7fffffff;   // reset the other parity for the next step
+        PS_LDS_BARRIER();
         double cs = x - run;
-        const double r = rnd[(size_t)k * T + (T - 1 - i)];
+        for (int ww = 0; ww < w; ww++) cs += s_run[par][ww];
+        const double r = rcur;
         int pick = 0x7fffffff;
 #pragma unroll
-        for (int m = 0; m < 16; m++) { cs += pr[m]; if (pick == 0x7fffffff && r < cs) pick = 16 * l + m; }
+        for (int m = 0; m < 4; m++) { cs += pr[m]; if (pick == 0x7fffffff && r < cs) pick = 4 * t + m; }
         for (int off = 32; off; off >>= 1) pick = min(pick, __shfl_xor(pick, off));
-        cur = pick == 0x7fffffff ? NS - 1 : pick;
-#pragma unroll
-        for (int m = 0; m < 16; m++) lf[m] = nx[m];
+        if (l == 0 && pick != 0x7fffffff) atomicMin(&s_pick[par], pick);
+        PS_LDS_BARRIER();
+        const int pk = s_pick[par];
+        cur = pk == 0x7fffffff ? NS - 1 : pk;
+        lf = nx; rcur = rnx;
     }
 }
 
@@ -241,18 +307,20 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
     if (E > VMAXE) return fail(PS_ERR_UNSUPPORTED, "ViterbiMutate: more than 64 events");
     PS_TRY(rt->buf("vit_in").ensure((size_t)T * E * 4 * sizeof(double)));
     PS_TRY(rt->buf("vit_obs").ensure((size_t)T * NS * sizeof(double)));
+    PS_TRY(rt->buf("vit_eobs").ensure((size_t)T * NS * sizeof(double)));
     PS_TRY(rt->buf("vit_bp").ensure((size_t)T * NS * sizeof(short)));
     PS_TRY(rt->buf("vit_fwd").ensure((size_t)(nkeep ? T : 1) * NS * sizeof(double)));
     PS_TRY(rt->buf("vit_lik").ensure(NS * sizeof(double)));
     double* d_in = rt->buf("vit_in").as<double>();
     double* d_obs = rt->buf("vit_obs").as<double>();
+    double* d_eobs = rt->buf("vit_eobs").as<double>();
     short* d_bp = rt->buf("vit_bp").as<short>();
     double* d_fwd = rt->buf("vit_fwd").as<double>();
     double* d_lik = rt->buf("vit_lik").as<double>();
     PS_HIP(hipMemcpyAsync(d_in, h_obsin, (size_t)T * E * 4 * sizeof(double), hipMemcpyHostToDevice, rt->stream));
     prof_begin(rt);
-    hipLaunchKernelGGL(k_vit_obs, dim3(T), dim3(256), 0, rt->stream, d_in, d_model, E, std::log(2 * M_PI), d_obs);
-    hipLaunchKernelGGL(k_vit_steps, dim3(1), dim3(1024), 0, rt->stream, d_obs, T, skip, stay, std::log(skip), std::log(stay),
+    hipLaunchKernelGGL(k_vit_obs, dim3(T), dim3(256), 0, rt->stream, d_in, d_model, E, std::log(2 * M_PI), d_obs, d_eobs);
+    hipLaunchKernelGGL(k_vit_steps, dim3(1), dim3(1024), 0, rt->stream, d_obs, d_eobs, T, skip, stay, std::log(skip), std::log(stay),
                        std::log(0.25), d_bp, d_fwd, d_lik, nkeep ? 1 : 0);
     PS_HIP(hipGetLastError());
     std::vector<double> lik(NS);
@@ -277,7 +345,8 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
     PS_TRY(rt->buf("vit_path").ensure((size_t)nkeep * T * sizeof(short)));
     PS_HIP(hipMemcpyAsync(rt->buf("vit_att").p, att.data(), nkeep * sizeof(double), hipMemcpyHostToDevice, rt->stream));
     PS_HIP(hipMemcpyAsync(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * T * sizeof(double), hipMemcpyHostToDevice, rt->stream));
-    hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(64), 0, rt->stream, d_fwd, T, start, skip, stay,
+    hipLaunchKernelGGL(k_vit_log, dim3((unsigned)(((size_t)T * NS + 255) / 256)), dim3(256), 0, rt->stream, d_fwd, (size_t)T * NS);
+    hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(256), 0, rt->stream, d_fwd, T, start, skip, stay,
                        rt->buf("vit_att").as<double>(), rt->buf("vit_rnd").as<double>(), rt->buf("vit_path").as<short>());
     PS_HIP(hipGetLastError());
     prof_end(rt, "viterbi", (double)T * NS * (8.0 * E + 8 + 2 + 8 + 8.0 * nkeep));
