@@ -253,6 +253,7 @@ static std::string path_to_bases(const std::vector<int>& st) {
 int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, double mmin, double mmax,
                    std::vector<std::string>* out) {
     out->clear();
+    Tick tk("viterbi_mutate");
     const int E = a->E;
     // host mirrors of ref_align / ref_index / refstart / refend
     PS_TRY(a->refs_to_host(rt));
@@ -261,21 +262,34 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
     PS_HIP(hipMemcpyAsync(h_ri.data(), a->d_ri, a->ntot * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
     PS_HIP(hipMemcpyAsync(info.data(), a->d_out, E * sizeof(JobOut), hipMemcpyDeviceToHost, rt->stream));
     PS_HIP(hipStreamSynchronize(rt->stream));
-    // first level whose ref_index equals an integer position (std::find in getrefstates, cpp/EventData.h:192)
-    std::vector<std::map<int, int>> first(E);
-    int maxref = 0;
+    tk.lap("refs D2H");
+    // first level whose ref_index equals an integer position (std::find in getrefstates, cpp/EventData.h:192),
+    // as a flat table per event indexed by position (positions outside [0, maxpos] never match)
+    // (extrapolated ref_index values past refend can be integers too and do take part, so the table
+    // spans every integer-valued entry)
+    int maxpos = 0;
     for (int e = 0; e < E; e++) {
-        if (!info[e].has_index) continue;  // empty ref_index: getrefstates finds nothing
+        if (!info[e].has_index) continue;
         const double* ri = h_ri.data() + a->off[e];
         for (int t = 0; t < a->n[e]; t++) {
             const double v = ri[t];
-            if (v == std::floor(v) && std::fabs(v) < 2e9) {
-                const int iv = (int)v;
-                if (!first[e].count(iv)) first[e][iv] = t;
-                maxref = std::max(maxref, iv);
+            if (v >= 0.0 && v < 1e9 && v == std::floor(v)) maxpos = std::max(maxpos, (int)v);
+        }
+    }
+    std::vector<std::vector<int>> first(E);
+    for (int e = 0; e < E; e++) {
+        if (!info[e].has_index) continue;  // empty ref_index: getrefstates finds nothing
+        first[e].assign((size_t)maxpos + 1, -1);
+        const double* ri = h_ri.data() + a->off[e];
+        for (int t = 0; t < a->n[e]; t++) {
+            const double v = ri[t];
+            if (v >= 0.0 && v <= (double)maxpos && v == std::floor(v)) {
+                int& slot = first[e][(size_t)v];
+                if (slot < 0) slot = t;
             }
         }
     }
+    tk.lap("first-index maps");
     auto rstart = [&](int e) { return info[e].has_index ? info[e].refstart : -1; };
     auto rend = [&](int e) { return info[e].has_index ? info[e].refend : -1; };
     int refind = rstart(0);
@@ -287,12 +301,11 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
         const size_t at = obsin.size();
         obsin.resize(at + (size_t)E * 4, 0.0);
         for (int e = 0; e < E; e++) {
-            auto it = first[e].find(refind);
-            if (it == first[e].end()) continue;
+            if (refind < 0 || refind > maxpos || first[e].empty() || first[e][refind] < 0) continue;
             const double* ra = a->h_ra.data() + a->off[e];
             const double* mean = a->h_mean.data() + a->off[e];
             const double* stdv = a->h_stdv.data() + a->off[e];
-            int t = it->second, cnt = 1;
+            int t = first[e][refind], cnt = 1;
             double lvl = mean[t], sd = stdv[t];
             // getrefstates keeps following levels while ref_align <= refind, using those > 0 (cpp/EventData.h:197-201)
             double lsum = 0, ssum = 0;
@@ -314,13 +327,17 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
         T++;
         refind++;
     }
+    tk.lap("gather levels");
     if (T == 0) return PS_OK;
     // uniform deviates in the reference's call order: for each kept path, one per back-step (cpp/Viterbi.cpp:108)
     std::vector<double> rnd((size_t)nkeep * T);
     for (size_t k = 0; k < rnd.size(); k++) rnd[k] = rand() / (double(RAND_MAX) + 1);
+    tk.lap("rand");
     std::vector<std::vector<int>> paths;
     PS_TRY(viterbi_device(rt, E, T, obsin.data(), a->d_model, nkeep, skip, stay, mmin, mmax, rnd.data(), &paths));
+    tk.lap("device");
     for (auto& p : paths) out->push_back(path_to_bases(p));
+    tk.lap("paths to bases");
     return PS_OK;
 }
 

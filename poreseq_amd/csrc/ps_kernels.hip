@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
 // ------------------------------------------------------------------------------------------------
 // backtrace (cpp/Alignment.cpp:516-624): one wave per job, 16x16 tiles staged in LDS
 // ------------------------------------------------------------------------------------------------
-constexpr int BT = 32;   // tile edge of the backtrace
+constexpr int BT = 48;   // tile edge of the backtrace
 
 __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
     const JobD& J = b.jobs[blockIdx.x];
@@ -513,45 +513,54 @@ __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
     __syncthreads();
     const double2* __restrict__ rec = b.rec + J.mat_off[0];
     const unsigned short* __restrict__ flg = b.flg + J.mat_off[0];
-    __shared__ double t_main[BT][BT + 1], t_stay[BT][BT + 1];
+    __shared__ double2 t_rec[BT][BT + 1];
     __shared__ unsigned short t_step[BT][BT + 2];
     __shared__ int s_state[4];
     int i = O.bi, j = O.bj, arr = 0;
     bool done = (i <= 0);
     while (!done) {
         const int ti = i, tj = j;
-#pragma unroll
-        for (int q = 0; q < BT * BT / 256; q++) {
-            const int idx = tid + 256 * q, a = idx / BT, c = idx % BT;
+        for (int idx = tid; idx < BT * BT; idx += 256) {
+            const int a = idx / BT, c = idx % BT;
             const int r = ti - a, col = tj - c;
-            double m = 0.0, s = 0.0; unsigned short st = 0;
+            double2 v = make_double2(0.0, 0.0); unsigned short st = 0;
             if (r >= 1 && col >= 1) {
                 const int64_t at = (int64_t)(r + col) * P + slot_of(r, P);
-                const double2 v = rec[at];
-                m = v.x; s = v.y; st = flg[at];
+                v = rec[at]; st = flg[at];
             }
-            t_main[a][c] = m; t_stay[a][c] = s; t_step[a][c] = st;
+            t_rec[a][c] = v; t_step[a][c] = st;
         }
         __syncthreads();
         if (tid == 0) {
+            int a = 0, c = 0;
+            double2 v = t_rec[0][0];
+            unsigned stp = t_step[0][0];
             while (true) {
-                const int a = ti - i, c = tj - j;
+                // the three possible successors, fetched while this cell is decoded
+                const int a1 = min(a + 1, BT - 1), c1 = min(c + 1, BT - 1);
+                const double2 vL = t_rec[a][c1];  const unsigned sL = t_step[a][c1];    // (i, j-1)
+                const double2 vD = t_rec[a1][c1]; const unsigned sD = t_step[a1][c1];   // (i-1, j-1)
+                const double2 vU = t_rec[a1][c];  const unsigned sU = t_step[a1][c];    // (i-1, j)
                 if (i <= 0) { done = true; break; }
-                if (a >= BT || c >= BT) break;  // next tile
-                const unsigned stp = t_step[a][c];
                 const unsigned st = arr ? (stp >> 8) : (stp & 255u);
-                const double sc = arr ? t_stay[a][c] : t_main[a][c];
+                const double sc = arr ? v.y : v.x;
                 if (sc <= 0.0) { done = true; break; }
-                if (st == M_SKIP) { j--; }
-                else if (st == M_MATCH) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; j--; }
-                else if (st == M_IGNORE) { ra[i - 1] = -1.0; rl[i - 1] = sc; i--; j--; }
-                else if (st == M_INSERT) { ra[i - 1] = -1.0; rl[i - 1] = sc; i--; }
+                int mv;  // 0 stay on the cell, 1 left, 2 diagonal, 3 up
+                if (st == M_SKIP) { mv = 1; }
+                else if (st == M_MATCH) { ra[i - 1] = (double)j; rl[i - 1] = sc; mv = 2; }
+                else if (st == M_IGNORE) { ra[i - 1] = -1.0; rl[i - 1] = sc; mv = 2; }
+                else if (st == M_INSERT) { ra[i - 1] = -1.0; rl[i - 1] = sc; mv = 3; }
                 else if (st == M_STAY) {
-                    if (arr == 1) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
+                    mv = 0;
+                    if (arr == 1) { ra[i - 1] = (double)j; rl[i - 1] = sc; mv = 3; }
                     arr = 1 - arr;
                 }
-                else if (st == M_EXTEND) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
+                else if (st == M_EXTEND) { ra[i - 1] = (double)j; rl[i - 1] = sc; mv = 3; }
                 else { done = true; break; }
+                if (mv == 1) { j--; c++; v = vL; stp = sL; }
+                else if (mv == 2) { i--; j--; a++; c++; v = vD; stp = sD; }
+                else if (mv == 3) { i--; a++; v = vU; stp = sU; }
+                if (a >= BT || c >= BT) break;  // left the tile: reload around (i, j)
             }
             s_state[0] = i; s_state[1] = j; s_state[2] = arr; s_state[3] = done ? 1 : 0;
         }

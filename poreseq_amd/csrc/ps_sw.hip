@@ -15,7 +15,7 @@
 
 namespace ps {
 
-constexpr int TC = 256;
+constexpr int TC = 64;
 constexpr int TSTEPS = ((TC + 63 + 3) / 4) * 4;   // steps per tile, padded to whole 4-step store groups
 
 struct SwPair {
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(64) void k_sw_tiles(const SwPair* pairs, const char
     int h = left;                                  // running H(i, j) of this lane
     int prevup = shr1_i(left);                     // H(i-1, j0)
     if (l == 0) prevup = s_top[0];
-    int best = 0, bestj = 0;
+    int best = 0, bestt = 0;
+    // columns this lane really has: jj in [0, ncl); it works on them at steps t = l + jj
+    const int ncl = rowok ? min(max(p.n2 - j0, 0), TC) : 0;
     // step codes: 4 consecutive steps of a lane are packed into one 32-bit store, [t/4][lane][t%4]
     unsigned* st = (unsigned*)(steps + p.steps_off + (int64_t)(r * p.ntc + c) * TSTEPS * 64);
     for (int t0 = 0; t0 < TSTEPS; t0 += 4) {
@@ -73,39 +75,31 @@ __global__ __launch_bounds__(64) void k_sw_tiles(const SwPair* pairs, const char
             ch[u] = s_c2[min(max(t - l, 0), TC - 1)];
         }
         unsigned packed = 0;
-        int bots[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = t0 + u;
-            const int jj = t - l;
+            const bool act = (unsigned)(t - l) < (unsigned)ncl;
             int up = shr1_i(h);
             if (l == 0) up = tops[u];
             const int diag = prevup;
             prevup = up;
-            unsigned code = 0;
-            bots[u] = 0;
-            if (t < TSTEPS && jj >= 0 && jj < TC && rowok && j0 + 1 + jj <= p.n2) {
-                int score = 0, step = 0;
-                int s = h - 8;                       // from the left: H(i, j-1)
-                if (s > score) { score = s; step = 1; }
-                s = up - 8;                          // from above: H(i-1, j)
-                if (s > score) { score = s; step = 2; }
-                const bool eq = c1 == ch[u];
-                s = diag + (eq ? 5 : -4);
-                if (s >= score) { score = s; step = 3; }
-                h = score;
-                code = (unsigned)(step | (score > 0 ? 4 : 0) | (eq ? 8 : 0));
-                if (score > best) { best = score; bestj = j0 + 1 + jj; }
-                bots[u] = score;
-            }
-            packed |= code << (8 * u);
+            // reference order (cpp/swlib.cpp:243-263): left with >, up with >, diagonal with >=, floor 0
+            const bool eq = c1 == ch[u];
+            const int sd = diag + (eq ? 5 : -4);
+            const int sl = h - 8, su = up - 8;
+            const int l0 = max(sl, 0);
+            const int m = max(l0, su);
+            const int score = max(m, sd);
+            const unsigned step = sd >= m ? 3u : (su > l0 ? 2u : (sl > 0 ? 1u : 0u));
+            const unsigned code = step | (score > 0 ? 4u : 0u) | (eq ? 8u : 0u);
+            packed |= act ? code << (8 * u) : 0u;
+            if (act && score > best) { best = score; bestt = t; }
+            h = act ? score : h;
+            if (l == 63 && t >= 63) s_bot[min(t - 63, TC - 1)] = h;
         }
-        if (t0 < TSTEPS) st[(t0 >> 2) * 64 + l] = packed;
-        if (l == 63) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int jj = t0 + u - 63; if (jj >= 0 && jj < TC) s_bot[jj] = bots[u]; }
-        }
+        st[(t0 >> 2) * 64 + l] = packed;
     }
+    const int bestj = j0 + 1 + (bestt - l);
     if (rowok) hc[i] = h;
     // tile maximum: largest score, then smallest column, then smallest row (column-major first hit)
     int bi = i, bj = best > 0 ? bestj : 0x7fffffff, bs = best;
@@ -156,17 +150,23 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const unsi
         for (int k = l; k < TSTEPS * 4; k += 64) dst[k] = src[k];
         __syncthreads();
         if (l == 0) {
+            auto code_at = [&](int ll, int jj) -> unsigned {   // clamped: callers check the real bounds
+                ll = max(ll, 0); jj = max(jj, 0);
+                const int tt = jj + ll;
+                return s_t[((tt >> 2) * 64 + ll) * 4 + (tt & 3)];
+            };
+            int ll = i - i0 - 1, jj = j - j0 - 1;
+            unsigned code = code_at(ll, jj);
             while (true) {
                 if (!(i > 0 && j > 0)) { done = true; break; }
-                const int ll = i - i0 - 1, jj = j - j0 - 1;
                 if (ll < 0 || jj < 0) break;  // left this tile
-                const int tt = jj + ll;
-                const unsigned code = s_t[((tt >> 2) * 64 + ll) * 4 + (tt & 3)];
+                // the three possible successors, fetched while this cell is decoded
+                const unsigned cL = code_at(ll, jj - 1), cD = code_at(ll - 1, jj - 1), cU = code_at(ll - 1, jj);
                 if (!(code & 4)) { done = true; break; }   // score <= 0
                 const unsigned stp = code & 3;
-                if (stp == 1) { oi[np] = 0; oj[np] = j; np++; j--; }
-                else if (stp == 2) { oi[np] = i; oj[np] = 0; np++; i--; }
-                else if (stp == 3) { oi[np] = i; oj[np] = j; np++; if (code & 8) nm++; i--; j--; }
+                if (stp == 1) { oi[np] = 0; oj[np] = j; np++; j--; jj--; code = cL; }
+                else if (stp == 2) { oi[np] = i; oj[np] = 0; np++; i--; ll--; code = cU; }
+                else if (stp == 3) { oi[np] = i; oj[np] = j; np++; if (code & 8) nm++; i--; j--; ll--; jj--; code = cD; }
                 else { done = true; break; }
             }
         }

@@ -8,9 +8,8 @@
 //                of a destination state depend only on its low bits, so the per-family maximum,
 //                its first index and the forward-probability sum are computed once per family
 //                (336 families) instead of once per state.  The first-strict-maximum rule of the
-//                reference is kept exactly: a family also remembers its second-largest value, and a
-//                destination state falls back to the plain ordered scan in the (sub-ulp) case where
-//                that value would round to the same sum as the maximum.
+//                reference is kept exactly: a destination state falls back to the plain ordered scan in
+//                the (sub-ulp) case where a value just below the family maximum would round to the same sum.
 //   k_vit_trace  nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131), one block each;
 //                the uniform deviates are drawn on the host from libc rand() in the reference's
 //                call order.
@@ -71,21 +70,23 @@ __global__ __launch_bounds__(256) void k_vit_obs(const double* __restrict__ obsi
 
 // Statistics of one predecessor family (the 4 / 16 / 64 states a destination can come from with a
 // 1 / 2 / 3-base advance): maximum of the previous Viterbi scores, the SMALLEST state index among the
-// maxima (= the first one the reference's ordered scan meets, since it scans in ascending state order),
+// maxima (= the first one the reference's ordered scan meets, since it scans in ascending state order)
 // the largest value strictly below the maximum, and the sum of the previous forward probabilities.
-// All four combine commutatively, and the families nest (state mod 256 -> mod 64 -> mod 16).
-struct Fam { double mx, second, psum; int idx; int pad; };
+// All four combine commutatively.
+struct Fam { double mx, second, psum; int idx; int pad; };   // second: largest value strictly below mx
 
 __device__ __forceinline__ Fam fam_join(const Fam& A, const Fam& B) {
     Fam r;
-    const double s2 = A.second > B.second ? A.second : B.second;
-    if (B.mx > A.mx) { r.mx = B.mx; r.idx = B.idx; r.second = A.mx > s2 ? A.mx : s2; }
-    else if (B.mx < A.mx) { r.mx = A.mx; r.idx = A.idx; r.second = B.mx > s2 ? B.mx : s2; }
-    else { r.mx = A.mx; r.idx = A.idx < B.idx ? A.idx : B.idx; r.second = s2; }
+    r.mx = fmax(A.mx, B.mx);
+    const int ia = A.mx == r.mx ? A.idx : 0x7fffffff, ib = B.mx == r.mx ? B.idx : 0x7fffffff;
+    r.idx = min(ia, ib);
+    const double lower = A.mx == B.mx ? -BIG * 10 : fmin(A.mx, B.mx);
+    r.second = fmax(fmax(A.second, B.second), lower);
     r.psum = A.psum + B.psum;
     r.pad = 0;
     return r;
 }
+
 // DPP row shift: lane i receives lane i + N of its 16-lane row (zero past the row end)
 template <int N>
 __device__ __forceinline__ double row_shl(double v) {
@@ -111,30 +112,49 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (lane_d(0) + lane_d(16)) + (lane_d(32) + lane_d(48));
 }
 
+// next double below x (x finite, non-zero)
+__device__ __forceinline__ double below(double x) {
+    long long b = __double_as_longlong(x);
+    b += x < 0.0 ? 1 : -1;
+    return __longlong_as_double(b);
+}
+
+#define VPAD(q) ((q) + ((q) >> 5))   // LDS padding: the 16/64/256-strided family reads stay conflict-free
+
 // families: s_fam[0..255] (1-base advance, key = state mod 256), [256..319] (2-base, mod 64), [320..335] (3-base, mod 16)
+// computed concurrently by waves 0-3, 4-7 and 8-11 straight from the previous score vector.
+//
+// Exactness of the back-pointers.  The reference takes, per destination c and advance length j, the
+// first predecessor (ascending state order) whose fl(a + lik[p]) is largest, a = obs[c] + log-weight.
+// fl(a + x) is monotone in x, so that is the smallest-index maximum of the family — unless a SMALLER
+// value rounds to the same sum.  That can only happen if fl(a + second) == fl(a + mx), second being the
+// family's largest value below its maximum; in that (sub-ulp) case the destination falls back to the
+// reference's ordered scan.
 //
 // Forward probabilities: the reference renormalises the 1024-vector after every step
 // (normvec, cpp/Viterbi.cpp:101).  Only ratios within one step's vector are ever used (randbp
-// renormalises its own products), so here each step is rescaled by an exact power of two taken from
-// the PREVIOUS step's total: the vector stays in range, no rounding is added, and the reduce -> divide
-// chain leaves the per-step critical path.
+// renormalises its own products), so here the vector is rescaled every 8 steps by an exact power of
+// two: it stays in range, no rounding is added, and no reduce -> divide chain sits on the step path.
 __global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ obs, const double* __restrict__ eobs, int T, double skip, double stay,
                                                     double lskip, double lstay, double l25,
                                                     short* __restrict__ bp, double* __restrict__ lfwd_out,
                                                     double* __restrict__ lik_final, int keep_fwd) {
-    __shared__ double s_lik[2][NS], s_fwd[2][NS];
+    __shared__ double s_lik[2][NS + NS / 32], s_fwd[2][NS + NS / 32];
     __shared__ Fam s_fam[336];
-    __shared__ double s_red[2][16];
+    __shared__ double s_red[16];
+    __shared__ double s_scale;
     const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
-    s_lik[0][c] = 0.0;
-    s_fwd[0][c] = 1.0 / NS;
-    if (c < 32) s_red[c >> 4][c & 15] = 1.0 / 16;   // "previous total" of the initial vector: 1
+    s_lik[0][VPAD(c)] = 0.0;
+    s_fwd[0][VPAD(c)] = 1.0 / NS;
+    if (c == 0) s_scale = 1.0;
     __syncthreads();
     const double sp1 = 0.25, sp2 = sp1 * 0.25 * skip, sp3 = sp2 * 0.25 * skip;
     const double lsp1 = l25, lsp2 = lsp1 + l25 + lskip, lsp3 = lsp2 + l25 + lskip;
-    // family pass layout for threads u < 256: u = 16 g3 + 4 m2 + m  ->  g2 = g3 + 16 m2, g1 = g2 + 64 m
-    const int fg3 = c >> 4, fm2 = (c >> 2) & 3, fm = c & 3;
-    const int fg2 = fg3 + 16 * fm2, fg1 = fg2 + 64 * fm;
+    // family-pass role of this thread: level fj (0 = none), family fg, 4 members q = fq0 + k * fqs
+    int fj = 0, fg = 0, fq0 = 0, fqs = 0;
+    if (c < 256) { fj = 1; fg = c; fq0 = c; fqs = 256; }
+    else if (c < 512) { const int u = c - 256; fj = 2; fg = u >> 2; fq0 = fg + 256 * (u & 3); fqs = 64; }
+    else if (c < 768) { const int u = c - 512; fj = 3; fg = u >> 4; fq0 = fg + 64 * (u & 15); fqs = 16; }
     int cur = 0;
     constexpr int VPF = 4;   // steps of obs / exp(obs) kept in flight in registers
     double oA[VPF], eA[VPF], oB[VPF], eB[VPF];
@@ -151,37 +171,33 @@ __global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ o
     auto vit_one = [&](const int t, const double o, const double eo) {
         const double* pl = s_lik[cur];
         const double* pf = s_fwd[cur];
-        // power-of-two rescale from the previous step's total (all lanes read the same 16 partials)
-        double ptot = 0.0;
+        const bool rescale = (t & 7) == 7;
+        if (fj) {
+            Fam m[4];
 #pragma unroll
-        for (int w = 0; w < 16; w++) ptot += s_red[cur][w];
-        int ex;
-        frexp(ptot, &ex);
-        const double scale = ldexp(1.0, -ex);
-        if (c < 256) {
-            Fam f;
-            f.mx = pl[fg1]; f.idx = fg1; f.second = -BIG * 10; f.psum = pf[fg1]; f.pad = 0;
-#pragma unroll
-            for (int k = 1; k < 4; k++) {
-                Fam g;
-                const int q = fg1 + (k << 8);
-                g.mx = pl[q]; g.idx = q; g.second = -BIG * 10; g.psum = pf[q]; g.pad = 0;
-                f = fam_join(f, g);
+            for (int k = 0; k < 4; k++) {
+                const int q = fq0 + k * fqs;
+                m[k].mx = pl[VPAD(q)]; m[k].idx = q; m[k].second = -BIG * 10; m[k].psum = pf[VPAD(q)]; m[k].pad = 0;
             }
-            s_fam[fg1] = f;
-            f = fam_join(f, fam_shl<1>(f));
-            f = fam_join(f, fam_shl<2>(f));
-            if (fm == 0) s_fam[256 + fg2] = f;
-            f = fam_join(f, fam_shl<4>(f));
-            f = fam_join(f, fam_shl<8>(f));
-            if ((c & 15) == 0) s_fam[320 + fg3] = f;
+            Fam f = fam_join(fam_join(m[0], m[1]), fam_join(m[2], m[3]));
+            if (fj >= 2) { f = fam_join(f, fam_shl<1>(f)); f = fam_join(f, fam_shl<2>(f)); }
+            if (fj == 3) { f = fam_join(f, fam_shl<4>(f)); f = fam_join(f, fam_shl<8>(f)); }
+            const bool writer = fj == 1 || (fj == 2 && (c & 3) == 0) || (fj == 3 && (c & 15) == 0);
+            if (writer) s_fam[(fj == 1 ? 0 : fj == 2 ? 256 : 320) + fg] = f;
+        } else if (c == 1023 && rescale) {
+            // the vector written at the end of this step is divided by 2^e, e from the previous total
+            double ptot = 0.0;
+            for (int w = 0; w < 16; w++) ptot += s_red[w];
+            int ex;
+            frexp(ptot, &ex);
+            s_scale = ldexp(1.0, -ex);
         }
         PS_LDS_BARRIER();
         double best = -BIG; int bq = -1; double fsum = 0.0;
 #pragma unroll
         for (int j = 1; j <= 3; j++) {
-            const int g = c >> (2 * j);
-            const Fam& f = s_fam[(j == 1 ? 0 : j == 2 ? 256 : 320) + g];
+            const int g = j == 1 ? (c >> 2) : j == 2 ? (c >> 4) : (c >> 6);
+            const Fam f = s_fam[(j == 1 ? 0 : j == 2 ? 256 : 320) + g];
             const double a = o + (j == 1 ? lsp1 : j == 2 ? lsp2 : lsp3);
             const double m = a + f.mx;
             fsum += (j == 1 ? sp1 : j == 2 ? sp2 : sp3) * f.psum;
@@ -190,21 +206,24 @@ __global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ o
                 const int cnt = 1 << (2 * j), sh = 10 - 2 * j;
                 for (int k = 0; k < cnt; k++) {
                     const int q = g + (k << sh);
-                    const double l = a + pl[q];
+                    const double l = a + pl[VPAD(q)];
                     if (l > best) { best = l; bq = q; }
                 }
             } else if (m > best) { best = m; bq = f.idx; }
         }
         {
-            const double l = o + lstay + pl[c];
+            const double l = o + lstay + pl[VPAD(c)];
             if (l > best) { best = l; bq = c; }
-            fsum += stay * pf[c];
+            fsum += stay * pf[VPAD(c)];
         }
-        const double nf = fsum * eo * scale;
-        const double wsum = wave_sum(nf);
-        if (lane == 0) s_red[cur ^ 1][wave] = wsum;
-        s_lik[cur ^ 1][c] = best;
-        s_fwd[cur ^ 1][c] = nf;
+        double nf = fsum * eo;
+        if (rescale) nf *= s_scale;
+        if ((t & 7) == 6) {   // totals for the next rescale, one step ahead of their use
+            const double wsum = wave_sum(nf);
+            if (lane == 0) s_red[wave] = wsum;
+        }
+        s_lik[cur ^ 1][VPAD(c)] = best;
+        s_fwd[cur ^ 1][VPAD(c)] = nf;
         bp[(size_t)t * NS + c] = (short)bq;
         if (keep_fwd) lfwd_out[(size_t)t * NS + c] = nf;
         PS_LDS_BARRIER();
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ o
     }
 #undef VIT_LOAD
 #undef VIT_RUN
-    lik_final[c] = s_lik[cur][c];
+    lik_final[c] = s_lik[cur][VPAD(c)];
 }
 
 // T[cur][p] of buildT (cpp/Viterbi.cpp:134-168) in closed form: predecessor p is reached by a j-base
@@ -242,20 +261,40 @@ __global__ void k_vit_log(double* __restrict__ v, size_t n) {
     if (i < n) v[i] = log(v[i]);
 }
 
+// DPP row shift the other way: lane i receives lane i - N of its 16-lane row (zero below the row start)
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_get(double v, int l) {   // l wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// inclusive prefix sum over the 64 lanes of a wave (in lane order)
+__device__ __forceinline__ double wave_scan(double v, int lane) {
+    v += row_shr<1>(v); v += row_shr<2>(v); v += row_shr<4>(v); v += row_shr<8>(v);
+    const double t0 = lane_get(v, 15), t1 = lane_get(v, 31), t2 = lane_get(v, 47);
+    const int row = lane >> 4;
+    const double add = row == 0 ? 0.0 : row == 1 ? t0 : row == 2 ? t0 + t1 : (t0 + t1) + t2;
+    return v + add;
+}
+
 // nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131): one 256-thread block per path,
-// thread t owns states 4t .. 4t+3 (so running sums are in state order).  grid nkeep.
+// thread t owns states 4t .. 4t+3 (so running sums are in state order).  The reference normalises the
+// 1024 products and walks their running sum until it exceeds r; here the raw running sum is compared
+// with r * total (same choice up to rounding of the forward weights).  grid nkeep.
 __global__ __launch_bounds__(256) void k_vit_trace(const double* __restrict__ lfwd, int T, int start, double skip, double stay,
                                                   const double* __restrict__ atten, const double* __restrict__ rnd,
                                                   short* __restrict__ path) {
-    __shared__ double s_tot[2][4], s_run[2][4];
-    __shared__ int s_pick[2];
+    __shared__ double s_wtot[2][4];
+    __shared__ int s_pick[2][4];
     const int k = blockIdx.x, t = threadIdx.x, l = t & 63, w = t >> 6;
     const double at = atten[k];
     int cur = start;
     double4 lf = *(const double4*)(lfwd + (size_t)(T - 1) * NS + 4 * t);
     double rcur = rnd[(size_t)k * T];
-    if (t < 2) s_pick[t] = 0x7fffffff;
-    PS_LDS_BARRIER();
     for (int i = T - 1; i >= 0; i--) {
         const int par = i & 1;
         if (t == 0) path[(size_t)k * T + i] = (short)cur;
@@ -264,41 +303,32 @@ __global__ __launch_bounds__(256) void k_vit_trace(const double* __restrict__ lf
         if (i > 0) { nx = *(const double4*)(lfwd + (size_t)(i - 1) * NS + 4 * t); rnx = rnd[(size_t)k * T + (T - i)]; }
         double pr[4];
         const double lv[4] = {lf.x, lf.y, lf.z, lf.w};
-        double tot = 0.0;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const double tv = trans_weight(cur, 4 * t + m, skip, stay);
             pr[m] = tv == 0.0 ? 0.0 : tv * exp(at * lv[m]);
-            tot += pr[m];
         }
-        for (int off = 32; off; off >>= 1) tot += __shfl_xor(tot, off);
-        if (l == 0) s_tot[par][w] = tot;
+        const double c0 = pr[0], c1 = c0 + pr[1], c2 = c1 + pr[2], c3 = c2 + pr[3];
+        const double incl = wave_scan(c3, l);
+        if (l == 63) s_wtot[par][w] = incl;
         PS_LDS_BARRIER();
-        tot = 1.0 / (s_tot[par][0] + s_tot[par][1] + s_tot[par][2] + s_tot[par][3]);
-        double run = 0.0;
-#pragma unroll
-        for (int m = 0; m < 4; m++) { pr[m] *= tot; run += pr[m]; }
-        double x = run;
-        for (int off = 1; off < 64; off <<= 1) { const double y = __shfl_up(x, off); if (l >= off) x += y; }
-        if (l == 63) s_run[par][w] = x;
-        if (t == 0) s_pick[par ^ 1] = 0x7fffffff;   // reset the other parity for the next step
-        PS_LDS_BARRIER();
-        double cs = x - run;
-        for (int ww = 0; ww < w; ww++) cs += s_run[par][ww];
-        const double r = rcur;
+        const double w0 = s_wtot[par][0], w1 = s_wtot[par][1], w2 = s_wtot[par][2], w3 = s_wtot[par][3];
+        const double base = (w == 0 ? 0.0 : w == 1 ? w0 : w == 2 ? w0 + w1 : (w0 + w1) + w2) + (incl - c3);
+        const double thr = rcur * (((w0 + w1) + w2) + w3);
         int pick = 0x7fffffff;
-#pragma unroll
-        for (int m = 0; m < 4; m++) { cs += pr[m]; if (pick == 0x7fffffff && r < cs) pick = 4 * t + m; }
-        for (int off = 32; off; off >>= 1) pick = min(pick, __shfl_xor(pick, off));
-        if (l == 0 && pick != 0x7fffffff) atomicMin(&s_pick[par], pick);
+        if (thr < base + c3) pick = thr < base + c0 ? 4 * t : thr < base + c1 ? 4 * t + 1 : thr < base + c2 ? 4 * t + 2 : 4 * t + 3;
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(pick != 0x7fffffff);
+        int wpick = 0x7fffffff;
+        if (hit) wpick = __builtin_amdgcn_readlane(pick, __builtin_ctzll(hit));
+        if (l == 0) s_pick[par][w] = wpick;
         PS_LDS_BARRIER();
-        const int pk = s_pick[par];
+        const int p0 = s_pick[par][0], p1 = s_pick[par][1], p2 = s_pick[par][2], p3 = s_pick[par][3];
+        const int pk = p0 != 0x7fffffff ? p0 : p1 != 0x7fffffff ? p1 : p2 != 0x7fffffff ? p2 : p3;
         cur = pk == 0x7fffffff ? NS - 1 : pk;
         lf = nx; rcur = rnx;
     }
 }
 
-// -------------------------------------------------------------------------------------------------
 int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const double* d_model, int nkeep,
                    double skip, double stay, double mmin, double mmax, const double* h_rand,
                    std::vector<std::vector<int>>* paths) {
