@@ -180,7 +180,8 @@ int Batch::place(Runtime* rt, int P_) {
     int64_t mat_tot = 0;
     for (JobD& j : jobs) {
         j.P = P;
-        for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot; mat_tot += j.S * P; }
+        // + 8 spare anti-diagonals: k_recur's padded last prefetch group stores (and k_steps never reads) there
+        for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot; mat_tot += (j.S + 8) * P; }
     }
     cells = mat_tot;
     PS_TRY(rt->buf("rec").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double2)));

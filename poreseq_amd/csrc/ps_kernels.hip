@@ -247,36 +247,39 @@ __device__ __forceinline__ double wave_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
-constexpr int PF = 4;  // anti-diagonals per prefetch group (two groups ping-pong in registers)
+constexpr int PF = 4;        // anti-diagonals per prefetch group (two groups ping-pong in registers)
+constexpr int REC_PAD = 2 * PF;  // spare anti-diagonals behind every matrix: the padded last group stores there
 
 template <int DIR>
 struct RecurState {
-    double cm = 0.0, cs = 0.0, co = 0.0;   // this lane's latest main / stay / emission (0 when it had no cell)
-    double upm = 0.0, upo = 0.0;           // what the upper neighbour handed over one step ago
+    double cm = 0.0, cs = 0.0, co = 0.0;   // this lane's latest main / stay / emission
+    double upm = 0.0, upo = 0.0;           // what the upper neighbour published one step ago
     int par = 0;
 };
 
-// one anti-diagonal.  Memory operations are unconditional (inactive lanes store to a private dummy
-// slot) so that hipcc can count vmcnt exactly and the prefetch of later anti-diagonals stays in flight.
+// one anti-diagonal.  Every input is gated by a band flag (F_RL / F_RD / F_TOP), so a lane's registers
+// and its exchange slot may hold anything while it has no cell; the cell's result is stored
+// unconditionally ((s, slot) pairs outside the band are never read by anyone).  Neighbour values go
+// through LDS for all lanes alike: one ds_write + one ds_read per step instead of DPP shifts plus
+// separate lane-0 / lane-63 hand-over code.
 template <int DIR>
 __device__ __forceinline__ void recur_step(RecurState<DIR>& r, const double o, const unsigned f, double2* __restrict__ dst,
-                                           double (*xch)[16][4], const int lane, const int wave, const int wprev,
+                                           double4* __restrict__ xch, const int slot, const int up_slot, const int P,
                                            const double lsk, const double lst, const double lex, const double lin) {
     const double NINF = -__builtin_inf();
-    const bool act = f & F_ACT;
-    if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-        double um = wave_shr1(r.cm), us = wave_shr1(r.cs), uo = 0.0;
-        if (DIR) uo = wave_shr1(r.co);
-        if (lane == 0) { um = xch[r.par][wprev][0]; us = xch[r.par][wprev][1]; if (DIR) uo = xch[r.par][wprev][2]; }
-        // a lane can have served row i - P one step earlier: gate the left / diagonal inputs explicitly
+    if (__builtin_amdgcn_ballot_w64(f & F_ACT) != 0ull) {
+        // {main, stay[, emission]} of row i-1 after the previous step (the forward pass moves 16 bytes, the backward 32)
+        double4 u;
+        if (DIR) u = xch[r.par * P + up_slot];
+        else { const double2 u2 = ((const double2*)xch)[r.par * P + up_slot]; u = make_double4(u2.x, u2.y, 0.0, 0.0); }
         const double L = (f & F_RL) ? r.cm : 0.0;
         const double D = (f & F_RD) ? r.upm : 0.0;
         const double po = (f & F_RD) ? r.upo : 0.0;
-        r.upm = um;
-        if (DIR) r.upo = uo;
+        r.upm = u.x;
+        if (DIR) r.upo = u.z;
         const bool top = f & F_TOP;
-        const double ume = top ? NINF : um, use = top ? NINF : us;
-        const double eo = DIR == 0 ? o : uo;
+        const double ume = top ? NINF : u.x, use = top ? NINF : u.y;
+        const double eo = DIR == 0 ? o : u.z;
         const double cSTAY = ume + eo + lst;
         const double cEXT = use + eo + lex;
         const double cINS = ume + lin;
@@ -291,34 +294,30 @@ __device__ __forceinline__ void recur_step(RecurState<DIR>& r, const double o, c
         nm = fmax(nm, cINS);
         nm = fmax(nm, cIGN);
         nm = fmax(nm, ns);
-        const bool live = act && !(f & F_INV);
-        r.cm = live ? nm : 0.0;
-        r.cs = live ? ns : 0.0;
-        if (DIR) r.co = live ? o : 0.0;
-    } else {
-        // no cell for this wave on this anti-diagonal: keep the hand-over chain alive
-        r.upm = 0.0; r.upo = 0.0;
-        if (lane == 0) { r.upm = xch[r.par][wprev][0]; if (DIR) r.upo = xch[r.par][wprev][2]; }
-        r.cm = 0.0; r.cs = 0.0; r.co = 0.0;
+        const bool inv = f & F_INV;       // invalid 5-mer: the whole column is zero (cpp/Alignment.cpp:162-163)
+        r.cm = inv ? 0.0 : nm;
+        r.cs = inv ? 0.0 : ns;
+        if (DIR) r.co = inv ? 0.0 : o;
+        *dst = make_double2(r.cm, r.cs);
+        if (DIR) xch[(r.par ^ 1) * P + slot] = make_double4(r.cm, r.cs, r.co, 0.0);
+        else ((double2*)xch)[(r.par ^ 1) * P + slot] = make_double2(r.cm, r.cs);
     }
-    *dst = make_double2(r.cm, r.cs);
-    if (lane == 63) { xch[r.par ^ 1][wave][0] = r.cm; xch[r.par ^ 1][wave][1] = r.cs; if (DIR) xch[r.par ^ 1][wave][2] = r.co; }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     r.par ^= 1;
 }
 
 template <int DIR>
-__device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, double (*xch)[16][4]) {
-    const int P = J.P, slot = threadIdx.x, lane = slot & 63, wave = slot >> 6, NW = P >> 6;
-    const int wprev = (wave + NW - 1) % NW;
+__device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, double4* __restrict__ xch) {
+    const int P = J.P, slot = threadIdx.x;
+    const int up_slot = slot == 0 ? P - 1 : slot - 1;
     const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
     const double* __restrict__ em = b.em + J.mat_off[DIR] + slot;
     const unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR] + slot;
     double2* __restrict__ rec = b.rec + J.mat_off[DIR] + slot;
-    double2* __restrict__ dummy = b.dummy + (size_t)blockIdx.x * 1024 + slot;
     const int64_t S = J.S, SL = S - 1;
     RecurState<DIR> r;
-    if (lane == 63) { xch[0][wave][0] = 0.0; xch[0][wave][1] = 0.0; xch[0][wave][2] = 0.0; }
+    xch[slot] = make_double4(0.0, 0.0, 0.0, 0.0);
+    xch[P + slot] = make_double4(0.0, 0.0, 0.0, 0.0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     double eA[PF], eB[PF];
@@ -333,8 +332,7 @@ __device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, doubl
     _Pragma("unroll") for (int u = 0; u < PF; u++) {                        \
         const int64_t sv = (int64_t)(s0) + u;                               \
         const unsigned f = sv < S ? F[u] : 0u;                              \
-        double2* dst = (f & F_ACT) ? rec + sv * P : dummy;                  \
-        recur_step<DIR>(r, E[u], f, dst, xch, lane, wave, wprev, lsk, lst, lex, lin); \
+        recur_step<DIR>(r, E[u], f, rec + sv * P, xch, slot, up_slot, P, lsk, lst, lex, lin); \
     }
     PS_LOAD(eA, fA, 2)
     for (int64_t s0 = 2; s0 < S; s0 += 2 * PF) {   // every wave runs the same padded trip count
@@ -348,7 +346,7 @@ __device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, doubl
 }
 
 __global__ __launch_bounds__(1024) void k_recur(BatchD b, int ndir) {
-    __shared__ double xch[2][16][4];
+    extern __shared__ double4 xch[];   // [2][P]
     const int jd = blockIdx.x, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
     if (b.out[job].inert) return;
@@ -807,7 +805,7 @@ int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int
     hipLaunchKernelGGL(k_emis, dim3(nblk, b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     prof_begin(rt);
-    hipLaunchKernelGGL(k_recur, dim3(b.njobs * ndir), dim3(P), 0, rt->stream, b, ndir);
+    hipLaunchKernelGGL(k_recur, dim3(b.njobs * ndir), dim3(P), 2 * P * sizeof(double4), rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     prof_end(rt, "fill", 0.0);
     PS_HIP(hipMemsetAsync(b.cmax, 0, ncols * sizeof(double), rt->stream));
