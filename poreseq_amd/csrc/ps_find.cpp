@@ -6,13 +6,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "ps_host.h"
+#include "ps_sw.h"
 
 namespace ps {
-
-struct SwResult { int score = 0; double accuracy = 0; std::vector<int> a, b; };
-int sw_batch(Runtime* rt, const std::vector<std::pair<const std::string*, const std::string*>>& in, std::vector<SwResult>* out);
 
 static void fillinds(SwResult& al) {  // cpp/swlib.cpp:342-365
     if (al.a.empty()) return;
@@ -31,15 +30,19 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
     // re-align to the current sequence, keeping per-base cumulative likelihoods (cpp/FindMutations.cpp:28-29)
     std::vector<double> base(std::max<size_t>(L, 4) + 1, 0.0), sc(std::max(a->E, 1));
     Tick tk("find_mutations");
-    PS_TRY(score_alignments(rt, a, sc.data(), base.data()));
-    tk.lap("base realign");
     const int S = (int)seeds.size();
-    if (!S) return PS_OK;
-    // Smith-Waterman of the current sequence against every seed (MapAlignments, cpp/EventUtil.cpp:16)
+    // Smith-Waterman of the current sequence against every seed (MapAlignments, cpp/EventUtil.cpp:16):
+    // independent of the re-alignment below, so it runs concurrently on the second stream
     std::vector<std::pair<const std::string*, const std::string*>> pairs;
     for (const std::string& s : seeds) pairs.push_back({&a->bases, &s});
+    SwJob swjob;
+    PS_TRY(sw_launch(rt, pairs, &swjob));
+    const int rc_base = score_alignments(rt, a, sc.data(), base.data());
+    tk.lap("base realign");
     std::vector<SwResult> als;
-    PS_TRY(sw_batch(rt, pairs, &als));
+    PS_TRY(sw_finish(rt, &swjob, &als));   // always drain the second stream, even on failure above
+    PS_TRY(rc_base);
+    if (!S) return PS_OK;
     for (SwResult& al : als) fillinds(al);
     tk.lap("smith-waterman");
     // seeds whose likelihood vector is not cached yet get (seed x event) alignment jobs
@@ -73,7 +76,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             const size_t ns = q1 - q0;
             // remapped ref_align of every (seed, event) job, cpp/EventUtil.cpp:22-51
             std::vector<double> h_ra((size_t)ns * a->ntot);
-            for (size_t q = q0; q < q1; q++) {
+            auto remap_seed = [&](size_t q) {
                 const SwResult& al = als[need[q]];
                 double* dst = h_ra.data() + (q - q0) * a->ntot;
                 for (int64_t t = 0; t < a->ntot; t++) {
@@ -85,6 +88,12 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
                     }
                     dst[t] = v;
                 }
+            };
+            {   // one host thread per seed (pure index arithmetic on disjoint outputs)
+                std::vector<std::thread> th;
+                for (size_t q = q0 + 1; q < q1; q++) th.emplace_back(remap_seed, q);
+                remap_seed(q0);
+                for (std::thread& x : th) x.join();
             }
             tk.lap("remap (host)");
             DBuf& rb = rt->buf("seed_refs");

@@ -61,8 +61,9 @@ int runtime(Runtime** out) {
             if (dev < 0 || dev >= n) dev = 0;
             hipDeviceProp_t prop;
             if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-                hipStreamCreate(&R.stream) != hipSuccess || hipEventCreate(&R.ev0) != hipSuccess ||
-                hipEventCreate(&R.ev1) != hipSuccess) {
+                hipStreamCreate(&R.stream) != hipSuccess || hipStreamCreate(&R.stream2) != hipSuccess ||
+                hipEventCreate(&R.ev0) != hipSuccess || hipEventCreate(&R.ev1) != hipSuccess ||
+                hipEventCreate(&R.sw0) != hipSuccess || hipEventCreate(&R.sw1) != hipSuccess) {
                 state = -1; why = "HIP device initialisation failed";
             } else if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
                 state = -1; why = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
@@ -416,13 +417,13 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
     // distinct r0 = max(start - 3, 1)
     std::vector<int> r0s;
     {
-        std::map<int, int> idx;
+        std::vector<int> idx((size_t)std::max<int64_t>(L, 4) + 2, -1);   // r0 <= L - 3 for every edit that is not skipped
         for (int i = 0; i < M; i++) {
             if (h_skip[i]) { h_oldidx[i] = 0; continue; }
             const int r0 = std::max(muts[i].start - 3, 1);
-            auto it = idx.find(r0);
-            if (it == idx.end()) { it = idx.emplace(r0, (int)r0s.size()).first; r0s.push_back(r0); }
-            h_oldidx[i] = it->second;
+            int& at = idx[r0];
+            if (at < 0) { at = (int)r0s.size(); r0s.push_back(r0); }
+            h_oldidx[i] = at;
         }
     }
     // size classes by new-column count

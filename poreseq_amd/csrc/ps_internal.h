@@ -54,7 +54,8 @@ struct Runtime {
     bool ready = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream2 = nullptr;          // Smith-Waterman batches run here, concurrently with the alignment fills
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, sw0 = nullptr, sw1 = nullptr;
     std::map<std::string, DBuf> pool;
     std::map<std::string, Prof> prof;
     bool prof_on = false;

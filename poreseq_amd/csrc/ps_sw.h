@@ -1,0 +1,37 @@
+// ps_sw.h — host-visible types of the Smith-Waterman module (ps_sw.hip)
+#ifndef PS_SW_H_
+#define PS_SW_H_
+#include "ps_internal.h"
+
+namespace ps {
+
+struct SwPair {
+    int n1, n2, ntr, ntc;
+    int64_t s1_off, s2_off;      // into the character pool
+    int64_t steps_off;           // into the step pool: ntr*ntc tiles of TSTEPS*64 bytes
+    int64_t hrow_off;            // 3 * (n2 + 1) ints
+    int64_t hcol_off;            // n1 + 1 ints
+    int64_t tile_off;            // ntr*ntc int4 {score, i, j, 0}
+    int64_t out_off;             // 2 * (n1 + n2 + 2) ints: index pairs in walk order
+    int64_t res_off;             // 8 ints: score, bi, bj, npairs, nmatch
+};
+
+struct SwResult { int score = 0; double accuracy = 0; std::vector<int> a, b; };
+
+// an enqueued batch: host staging stays alive until sw_finish
+struct SwJob {
+    std::vector<SwPair> pairs;
+    std::string pool;
+    std::vector<int> res, outbuf;
+    int64_t out_tot = 0;
+    double cells = 0;
+    int np = 0;
+};
+
+typedef std::vector<std::pair<const std::string*, const std::string*>> SwInput;
+int sw_launch(Runtime* rt, const SwInput& in, SwJob* job);   // asynchronous, on rt->stream2
+int sw_finish(Runtime* rt, SwJob* job, std::vector<SwResult>* out);
+int sw_batch(Runtime* rt, const SwInput& in, std::vector<SwResult>* out);
+
+}  // namespace ps
+#endif

@@ -11,23 +11,12 @@
 // anti-diagonal, all sequence pairs of a batch in the same launch).
 // Step codes are stored per tile in the order they are produced ([t][lane], 64-byte coalesced
 // stores); the traceback pulls one whole tile into LDS and walks it there.
-#include "ps_internal.h"
+#include "ps_sw.h"
 
 namespace ps {
 
 constexpr int TC = 64;
 constexpr int TSTEPS = ((TC + 63 + 3) / 4) * 4;   // steps per tile, padded to whole 4-step store groups
-
-struct SwPair {
-    int n1, n2, ntr, ntc;
-    int64_t s1_off, s2_off;      // into the character pool
-    int64_t steps_off;           // into the step pool: ntr*ntc tiles of TSTEPS*64 bytes
-    int64_t hrow_off;            // 3 * (n2 + 1) ints
-    int64_t hcol_off;            // n1 + 1 ints
-    int64_t tile_off;            // ntr*ntc int4 {score, i, j, 0}
-    int64_t out_off;             // 2 * (n1 + n2 + 2) ints: index pairs in walk order
-    int64_t res_off;             // 8 ints: score, bi, bj, npairs, nmatch
-};
 
 __device__ __forceinline__ int shr1_i(int v) {
     return __builtin_amdgcn_update_dpp(v, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
@@ -178,14 +167,14 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const unsi
 }
 
 // -------------------------------------------------------------------------------------------------
-struct SwResult { int score = 0; double accuracy = 0; std::vector<int> a, b; };
-
-int sw_batch(Runtime* rt, const std::vector<std::pair<const std::string*, const std::string*>>& in, std::vector<SwResult>* out) {
+// enqueue a batch of pairwise alignments on the runtime's second stream (asynchronous)
+int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const std::string*>>& in, SwJob* job) {
     const int np = (int)in.size();
-    out->assign(np, SwResult());
+    job->np = np;
     if (!np) return PS_OK;
-    std::vector<SwPair> pairs(np);
-    std::string pool;
+    std::vector<SwPair>& pairs = job->pairs;
+    std::string& pool = job->pool;
+    pairs.assign(np, SwPair());
     int64_t steps_tot = 0, hrow_tot = 0, hcol_tot = 0, tile_tot = 0, out_tot = 0;
     int maxdiag = 0, maxtiles = 0;
     for (int k = 0; k < np; k++) {
@@ -202,8 +191,10 @@ int sw_batch(Runtime* rt, const std::vector<std::pair<const std::string*, const 
         p.res_off = (int64_t)k * 8;
         maxdiag = std::max(maxdiag, p.ntr + p.ntc - 1);
         maxtiles = std::max(maxtiles, std::min(p.ntr, p.ntc));
+        job->cells += (double)p.n1 * p.n2;
     }
     pool.push_back(0);
+    job->out_tot = out_tot;
     PS_TRY(rt->buf("sw_pairs").ensure(np * sizeof(SwPair)));
     PS_TRY(rt->buf("sw_chars").ensure(pool.size()));
     PS_TRY(rt->buf("sw_steps").ensure(steps_tot));
@@ -220,38 +211,55 @@ int sw_batch(Runtime* rt, const std::vector<std::pair<const std::string*, const 
     int4* d_tiles = rt->buf("sw_tiles").as<int4>();
     int* d_out = rt->buf("sw_out").as<int>();
     int* d_res = rt->buf("sw_res").as<int>();
-    PS_HIP(hipMemcpyAsync(d_pairs, pairs.data(), np * sizeof(SwPair), hipMemcpyHostToDevice, rt->stream));
-    PS_HIP(hipMemcpyAsync(d_chars, pool.data(), pool.size(), hipMemcpyHostToDevice, rt->stream));
-    PS_HIP(hipMemsetAsync(d_res, 0, (size_t)np * 8 * sizeof(int), rt->stream));
-    prof_begin(rt);
-    for (int d = 0; d < maxdiag; d++) {
-        hipLaunchKernelGGL(k_sw_tiles, dim3(maxtiles, np), dim3(64), 0, rt->stream, d_pairs, d_chars, d_steps, d_hrow, d_hcol, d_tiles, d);
-    }
+    hipStream_t st = rt->stream2;
+    PS_HIP(hipMemcpyAsync(d_pairs, pairs.data(), np * sizeof(SwPair), hipMemcpyHostToDevice, st));
+    PS_HIP(hipMemcpyAsync(d_chars, pool.data(), pool.size(), hipMemcpyHostToDevice, st));
+    PS_HIP(hipMemsetAsync(d_res, 0, (size_t)np * 8 * sizeof(int), st));
+    if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw0, st));
+    for (int d = 0; d < maxdiag; d++)
+        hipLaunchKernelGGL(k_sw_tiles, dim3(maxtiles, np), dim3(64), 0, st, d_pairs, d_chars, d_steps, d_hrow, d_hcol, d_tiles, d);
     PS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_sw_best, dim3(np), dim3(64), 0, rt->stream, d_pairs, d_tiles, d_res);
-    hipLaunchKernelGGL(k_sw_trace, dim3(np), dim3(64), 0, rt->stream, d_pairs, d_steps, d_out, d_res);
+    hipLaunchKernelGGL(k_sw_best, dim3(np), dim3(64), 0, st, d_pairs, d_tiles, d_res);
+    hipLaunchKernelGGL(k_sw_trace, dim3(np), dim3(64), 0, st, d_pairs, d_steps, d_out, d_res);
     PS_HIP(hipGetLastError());
-    double cells = 0;
-    for (auto& p : pairs) cells += (double)p.n1 * p.n2;
-    prof_end(rt, "sw", cells * 5.0);  // 4-byte score + 1-byte step per cell (the reference's footprint)
-    std::vector<int> res((size_t)np * 8);
-    PS_HIP(hipMemcpyAsync(res.data(), d_res, res.size() * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
-    PS_HIP(hipStreamSynchronize(rt->stream));
-    std::vector<int> tmp;
-    for (int k = 0; k < np; k++) {
-        const int n = res[k * 8 + 3], nm = res[k * 8 + 4];
-        SwResult& r = (*out)[k];
-        r.score = res[k * 8 + 0];
-        r.a.resize(n); r.b.resize(n);
-        if (n) {
-            PS_HIP(hipMemcpyAsync(r.a.data(), d_out + pairs[k].out_off, n * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
-            PS_HIP(hipMemcpyAsync(r.b.data(), d_out + pairs[k].out_off + (pairs[k].n1 + pairs[k].n2 + 2), n * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
+    if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw1, st));
+    job->res.resize((size_t)np * 8);
+    job->outbuf.resize((size_t)out_tot);
+    PS_HIP(hipMemcpyAsync(job->res.data(), d_res, job->res.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    PS_HIP(hipMemcpyAsync(job->outbuf.data(), d_out, (size_t)out_tot * sizeof(int), hipMemcpyDeviceToHost, st));
+    return PS_OK;
+}
+
+int sw_finish(Runtime* rt, SwJob* job, std::vector<SwResult>* out) {
+    const int np = job->np;
+    out->assign(np, SwResult());
+    if (!np) return PS_OK;
+    PS_HIP(hipStreamSynchronize(rt->stream2));
+    if (rt->prof_on) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, rt->sw0, rt->sw1) == hipSuccess) {
+            Prof& pr = rt->prof["sw"];
+            pr.ms += ms; pr.launches += 1; pr.bytes += job->cells * 5.0;  // 4-byte score + 1-byte step per cell (the reference's footprint)
         }
+    }
+    for (int k = 0; k < np; k++) {
+        const int n = job->res[k * 8 + 3], nm = job->res[k * 8 + 4];
+        const SwPair& p = job->pairs[k];
+        SwResult& r = (*out)[k];
+        r.score = job->res[k * 8 + 0];
+        const int* oi = job->outbuf.data() + p.out_off;
+        const int* oj = oi + (p.n1 + p.n2 + 2);
+        r.a.assign(oi, oi + n); r.b.assign(oj, oj + n);
+        std::reverse(r.a.begin(), r.a.end()); std::reverse(r.b.begin(), r.b.end());
         r.accuracy = 100.0 * nm / (double)n;  // NaN for an empty alignment, as the reference computes it
     }
-    PS_HIP(hipStreamSynchronize(rt->stream));
-    for (auto& r : *out) { std::reverse(r.a.begin(), r.a.end()); std::reverse(r.b.begin(), r.b.end()); }
     return PS_OK;
+}
+
+int sw_batch(Runtime* rt, const std::vector<std::pair<const std::string*, const std::string*>>& in, std::vector<SwResult>* out) {
+    SwJob job;
+    PS_TRY(sw_launch(rt, in, &job));
+    return sw_finish(rt, &job, out);
 }
 
 int sw_device(Runtime* rt, const std::string& s1, const std::string& s2, int* score, double* accuracy,
