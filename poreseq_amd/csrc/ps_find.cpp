@@ -37,6 +37,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
     for (const std::string& s : seeds) pairs.push_back({&a->bases, &s});
     SwJob swjob;
     PS_TRY(sw_launch(rt, pairs, &swjob));
+    tk.lap("sw enqueue");
     const int rc_base = score_alignments(rt, a, sc.data(), base.data());
     tk.lap("base realign");
     std::vector<SwResult> als;

@@ -43,6 +43,15 @@ int DBuf::ensure(size_t bytes) {
     return PS_OK;
 }
 
+int HBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return PS_OK;
+    if (p) { PS_HIP(hipHostFree(p)); p = nullptr; cap = 0; }
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+    PS_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return PS_OK;
+}
+
 int runtime(Runtime** out) {
     static Runtime R;
     static int state = 0;  // 0 untried, 1 ok, -1 failed
@@ -60,8 +69,12 @@ int runtime(Runtime** out) {
             else if (const char* s2 = getenv("LOCAL_RANK")) dev = atoi(s2) % n;
             if (dev < 0 || dev >= n) dev = 0;
             hipDeviceProp_t prop;
+            // Two non-blocking streams: alignment fills on one, Smith-Waterman batches on the other (they
+            // overlap inside FindMutations).  Partitioning the CUs between them (hipExtStreamCreateWithCUMask)
+            // was measured and made no difference, so it is not used.
             if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-                hipStreamCreate(&R.stream) != hipSuccess || hipStreamCreate(&R.stream2) != hipSuccess ||
+                hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&R.stream2, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreate(&R.ev0) != hipSuccess || hipEventCreate(&R.ev1) != hipSuccess ||
                 hipEventCreate(&R.sw0) != hipSuccess || hipEventCreate(&R.sw1) != hipSuccess) {
                 state = -1; why = "HIP device initialisation failed";

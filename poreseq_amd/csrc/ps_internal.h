@@ -48,6 +48,14 @@ struct DBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// grow-only pinned host buffer (hipHostMalloc): device->host copies into it are truly asynchronous
+struct HBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    template <class T> T* as() const { return (T*)p; }
+};
+
 struct Prof { double ms = 0; int64_t launches = 0; double bytes = 0; };
 
 struct Runtime {
@@ -57,6 +65,8 @@ struct Runtime {
     hipStream_t stream2 = nullptr;          // Smith-Waterman batches run here, concurrently with the alignment fills
     hipEvent_t ev0 = nullptr, ev1 = nullptr, sw0 = nullptr, sw1 = nullptr;
     std::map<std::string, DBuf> pool;
+    std::map<std::string, HBuf> hpool;
+    HBuf& hbuf(const std::string& name) { return hpool[name]; }
     std::map<std::string, Prof> prof;
     bool prof_on = false;
     DBuf& buf(const std::string& name) { return pool[name]; }

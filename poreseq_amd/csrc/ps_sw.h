@@ -22,7 +22,8 @@ struct SwResult { int score = 0; double accuracy = 0; std::vector<int> a, b; };
 struct SwJob {
     std::vector<SwPair> pairs;
     std::string pool;
-    std::vector<int> res, outbuf;
+    int* res = nullptr;        // pinned host staging (runtime-owned): results and index pairs
+    int* outbuf = nullptr;
     int64_t out_tot = 0;
     double cells = 0;
     int np = 0;

@@ -223,10 +223,12 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     hipLaunchKernelGGL(k_sw_trace, dim3(np), dim3(64), 0, st, d_pairs, d_steps, d_out, d_res);
     PS_HIP(hipGetLastError());
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw1, st));
-    job->res.resize((size_t)np * 8);
-    job->outbuf.resize((size_t)out_tot);
-    PS_HIP(hipMemcpyAsync(job->res.data(), d_res, job->res.size() * sizeof(int), hipMemcpyDeviceToHost, st));
-    PS_HIP(hipMemcpyAsync(job->outbuf.data(), d_out, (size_t)out_tot * sizeof(int), hipMemcpyDeviceToHost, st));
+    PS_TRY(rt->hbuf("sw_res").ensure((size_t)np * 8 * sizeof(int)));
+    PS_TRY(rt->hbuf("sw_out").ensure((size_t)out_tot * sizeof(int)));
+    job->res = rt->hbuf("sw_res").as<int>();
+    job->outbuf = rt->hbuf("sw_out").as<int>();
+    PS_HIP(hipMemcpyAsync(job->res, d_res, (size_t)np * 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PS_HIP(hipMemcpyAsync(job->outbuf, d_out, (size_t)out_tot * sizeof(int), hipMemcpyDeviceToHost, st));
     return PS_OK;
 }
 
@@ -247,7 +249,7 @@ int sw_finish(Runtime* rt, SwJob* job, std::vector<SwResult>* out) {
         const SwPair& p = job->pairs[k];
         SwResult& r = (*out)[k];
         r.score = job->res[k * 8 + 0];
-        const int* oi = job->outbuf.data() + p.out_off;
+        const int* oi = job->outbuf + p.out_off;
         const int* oj = oi + (p.n1 + p.n2 + 2);
         r.a.assign(oi, oi + n); r.b.assign(oj, oj + n);
         std::reverse(r.a.begin(), r.a.end()); std::reverse(r.b.begin(), r.b.end());

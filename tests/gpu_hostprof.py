@@ -11,5 +11,6 @@ def run():
     pa = PSAlign(); pa.sequence = draft; pa.events = copy.deepcopy(events); pa.params = dict(P)
     return consensus_region(pa, P)
 run()
+sys.stderr.write('=== MEASURED RUN ===\n'); sys.stderr.flush()
 pr = cProfile.Profile(); t = time.time(); pr.enable(); run(); pr.disable(); print("wall", time.time() - t)
 pstats.Stats(pr).sort_stats("tottime").print_stats(14)
