@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
 // ------------------------------------------------------------------------------------------------
 // backtrace (cpp/Alignment.cpp:516-624): one wave per job, 16x16 tiles staged in LDS
 // ------------------------------------------------------------------------------------------------
-constexpr int BT = 48;   // tile edge of the backtrace
+constexpr int BT = 32;   // tile edge of the backtrace (48 measured slower: 9 loads per thread per tile)
 
 __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
     const JobD& J = b.jobs[blockIdx.x];
@@ -530,35 +530,28 @@ __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
         }
         __syncthreads();
         if (tid == 0) {
-            int a = 0, c = 0;
-            double2 v = t_rec[0][0];
-            unsigned stp = t_step[0][0];
+            // Measured alternatives that did not pay: prefetching the three possible successor cells (more LDS
+            // reads than they hide), 48x48 tiles (9 loads per thread), and emitting whole diagonal MATCH runs
+            // per iteration (the run lengths cost k_steps as much as the walk saved).
             while (true) {
-                // the three possible successors, fetched while this cell is decoded
-                const int a1 = min(a + 1, BT - 1), c1 = min(c + 1, BT - 1);
-                const double2 vL = t_rec[a][c1];  const unsigned sL = t_step[a][c1];    // (i, j-1)
-                const double2 vD = t_rec[a1][c1]; const unsigned sD = t_step[a1][c1];   // (i-1, j-1)
-                const double2 vU = t_rec[a1][c];  const unsigned sU = t_step[a1][c];    // (i-1, j)
+                const int a = ti - i, c = tj - j;
                 if (i <= 0) { done = true; break; }
+                if (a >= BT || c >= BT) break;  // left the tile: reload around (i, j)
+                const unsigned stp = t_step[a][c];
+                const double2 v = t_rec[a][c];
                 const unsigned st = arr ? (stp >> 8) : (stp & 255u);
                 const double sc = arr ? v.y : v.x;
                 if (sc <= 0.0) { done = true; break; }
-                int mv;  // 0 stay on the cell, 1 left, 2 diagonal, 3 up
-                if (st == M_SKIP) { mv = 1; }
-                else if (st == M_MATCH) { ra[i - 1] = (double)j; rl[i - 1] = sc; mv = 2; }
-                else if (st == M_IGNORE) { ra[i - 1] = -1.0; rl[i - 1] = sc; mv = 2; }
-                else if (st == M_INSERT) { ra[i - 1] = -1.0; rl[i - 1] = sc; mv = 3; }
+                if (st == M_SKIP) { j--; }
+                else if (st == M_MATCH) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; j--; }
+                else if (st == M_IGNORE) { ra[i - 1] = -1.0; rl[i - 1] = sc; i--; j--; }
+                else if (st == M_INSERT) { ra[i - 1] = -1.0; rl[i - 1] = sc; i--; }
                 else if (st == M_STAY) {
-                    mv = 0;
-                    if (arr == 1) { ra[i - 1] = (double)j; rl[i - 1] = sc; mv = 3; }
+                    if (arr == 1) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
                     arr = 1 - arr;
                 }
-                else if (st == M_EXTEND) { ra[i - 1] = (double)j; rl[i - 1] = sc; mv = 3; }
+                else if (st == M_EXTEND) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
                 else { done = true; break; }
-                if (mv == 1) { j--; c++; v = vL; stp = sL; }
-                else if (mv == 2) { i--; j--; a++; c++; v = vD; stp = sD; }
-                else if (mv == 3) { i--; a++; v = vU; stp = sU; }
-                if (a >= BT || c >= BT) break;  // left the tile: reload around (i, j)
             }
             s_state[0] = i; s_state[1] = j; s_state[2] = arr; s_state[3] = done ? 1 : 0;
         }
