@@ -15,11 +15,19 @@
 // Storage is skewed: REC[s][i mod P].  One workgroup of P lanes owns one alignment and sweeps
 // s = 2 .. n0 + C; lane `slot` owns the row i == slot (mod P) that is inside the band on that
 // anti-diagonal (the band's footprint on one anti-diagonal is a contiguous run of at most
-// 2W + 1 <= P rows, because the band centre is a monotone function of the column).  Cell (i, j)
-// needs (i, j-1) = the lane's own previous value, (i-1, j) = the neighbour lane's previous
-// value (DPP wave shift; LDS hand-off across waves) and (i-1, j-1) = what the neighbour handed
-// over one step earlier.  Emission log-densities (three FP64 divisions each) do not take part in
-// the recurrence and are produced by a separate, chip-wide pass straight into REC.
+// 2W + 1 rows, because the band centre is a monotone function of the column; P is sized from the
+// measured footprint, typically ~half the band).  Cell (i, j) needs (i, j-1) = the lane's own
+// previous value, (i-1, j) = the neighbour lane's previous value and (i-1, j-1) = what the neighbour
+// published one step earlier; neighbour values travel through a double-buffered LDS array, one
+// s_barrier per anti-diagonal.  Pipeline per batch of alignments:
+//   k_lb / k_lo   band centres per column, lowest in-band row + footprint per anti-diagonal
+//   k_emis        chip-wide: emission log-densities (three FP64 divisions each) + band flags
+//   k_recur       the serial part: values only (fmax), flag-gated inputs, unconditional stores
+//   k_steps       chip-wide: back-pointer codes re-derived with the reference's ordered selection,
+//                 per-column maxima (LDS-aggregated atomics)
+//   k_prefix      running MaxInfo per column, first cell of the global maximum
+//   k_backtrace   LDS-tile walker, then k_updaterefs / k_lb for the new band centres
+//   k_old / k_score / k_reduce   edit scoring (scoreMutation + columnMax) and the per-edit sums
 #include "ps_internal.h"
 
 namespace ps {

@@ -1,0 +1,81 @@
+"""GPU parity at the `poreseq variant` shape (BASELINE config #3, scaled so the oracle finishes in seconds):
+ScoreMutations with scoring_width 100 on random point edits, through the variant driver's start offsetting."""
+import copy
+import io
+
+import numpy as np
+import pytest
+
+import backends as B
+from poreseq_amd import _capi, synth
+from poreseq_amd.consensus import variant_region, consensus_region, split_regions
+from poreseq_amd.poreseqcpp import PSAlign
+from poreseq_amd.util import DEFAULT_PARAMS, MutationInfo
+
+pytestmark = pytest.mark.gpu
+P0 = dict(DEFAULT_PARAMS, verbose=0)
+
+
+def test_variant_region_parity_and_format():
+    L, E = 1500, 12
+    draft, events, truth = synth.make_region(L, E, 71, B.oracle_swalign, P0)
+    rng = np.random.default_rng(71)
+    region_start = 9000
+    res = []
+    for cls in (PSAlign, B.OraclePSAlign):
+        muts = synth.random_point_mutations(np.random.default_rng(71), draft, 300)
+        for m in muts:
+            m.start += region_start            # absolute coordinates, as read from a mutation file
+        pa = B.make_pa(cls, draft, copy.deepcopy(events), P0)
+        out = io.StringIO()
+        ms = variant_region(pa, muts, region_start=region_start, out=out)
+        res.append((ms, out.getvalue()))
+    a, b = res
+    assert np.array_equal(np.array([m.score for m in a[0]]), np.array([m.score for m in b[0]]))
+    assert a[1] == b[1]
+    line = a[1].splitlines()[0].split("\t")
+    assert len(line) == 4 and int(line[0]) >= region_start          # start\torig\tmut\tscore, absolute start
+
+
+def test_all_points_when_mutation_list_is_empty():
+    draft, events, truth = synth.make_region(300, 5, 72, B.oracle_swalign, P0)
+    a = variant_region(B.make_pa(PSAlign, draft, copy.deepcopy(events), P0), [], region_start=100)
+    b = variant_region(B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), P0), [], region_start=100)
+    assert [m.start for m in a] == [m.start for m in b] and a[0].start == 100
+    assert np.array_equal(np.array([m.score for m in a]), np.array([m.score for m in b]))
+
+
+def test_consensus_driver_matches_oracle_with_end_trim():
+    P = dict(P0, end_trim=20.0)
+    draft, events, truth = synth.make_region(500, 8, 73, B.oracle_swalign, P)
+    out = []
+    for cls in (PSAlign, B.OraclePSAlign):
+        B.reset_rand()
+        pa = B.make_pa(cls, draft, copy.deepcopy(events), P)
+        log = []
+        seq, acc = consensus_region(pa, P, refseq=truth, log=log)   # accuracy against the synthetic truth
+        out.append((seq, acc, [(c, n) for c, n, _ in log]))
+    assert out[0] == out[1]
+    assert out[0][1] > 97.0 and len(out[0][0]) < len(draft)          # trimmed, accurate
+    # fewer than 5 events: the driver returns the input untouched (Mutate.py:50-53)
+    pa = B.make_pa(PSAlign, draft, copy.deepcopy(events[:4]), P)
+    assert consensus_region(pa, P) == (draft, 100)
+
+
+def test_unsupported_and_limits_fail_loudly():
+    draft, events, truth = synth.make_region(200, 3, 74, B.oracle_swalign, P0, draft_error=0.0)
+    api = _capi.load_hip()
+    big = [copy.deepcopy(events[k % 3]) for k in range(65)]      # ViterbiMutate handles at most 64 events
+    h = api.align_create(draft, big, P0)
+    with pytest.raises(_capi.PoreseqError):
+        api.viterbi_mutate(h, 16, 0.05, 0.01, 0.33, 0.75, 0)
+    api.align_destroy(h)
+    # realign_width 0 makes every alignment a no-op, exactly like the reference's stripe_width == 0
+    z = dict(P0, realign_width=0.0)
+    assert B.make_pa(PSAlign, draft, copy.deepcopy(events), z).ScoreEvents() == \
+        B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), z).ScoreEvents() == [0.0, 0.0, 0.0]
+    # scoring_width 0 disables the local re-fill (fillColumn returns at once): still identical
+    z = dict(P0, scoring_width=0.0, point_width=0.0)
+    a = B.make_pa(PSAlign, draft, copy.deepcopy(events), z).ScorePoints()
+    b = B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), z).ScorePoints()
+    assert np.array_equal(np.array([m.score for m in a]), np.array([m.score for m in b]))
