@@ -16,11 +16,15 @@ def init(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("PORESEQ_DEVICE", str(local))   # read by libporeseq_hip when it first touches the GPU
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("PORESEQ_FORCE_PG") == "1"     # tests: exercise the collective path on one GPU
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 

@@ -1,0 +1,54 @@
+"""GPU test of the distributed plumbing: bench.py launched through torch.distributed.run (as the driver does
+for N > 1) with one rank, and the RCCL gather path of poreseq_amd.dist forced on with a one-rank group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import backends as B
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_under_torchrun_single_rank():
+    env = dict(os.environ, PORESEQ_FORCE_PG="1")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(B.ROOT, "bench.py"),
+                                   "--gpus", "1", "--steps", "1", "--warmup", "0", "--length", "1000", "--no-cpu"],
+                                  env=env, timeout=900, stderr=subprocess.STDOUT)
+    line = [l for l in out.decode().splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["unit"] == "kb/s" and r["scaling"] == "weak"
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0
+    assert r["accuracy"]["consensus_percent"] > 97.0
+
+
+def test_rccl_gather_of_region_results():
+    code = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+os.environ["PORESEQ_FORCE_PG"] = "1"
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+os.environ["MASTER_PORT"] = "29519"
+from poreseq_amd import dist as psdist, synth
+from poreseq_amd.poreseqcpp import PSAlign, swalign
+from poreseq_amd.util import DEFAULT_PARAMS
+rank, local, world = psdist.init()
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+P = dict(DEFAULT_PARAMS, verbose=0)
+def process(reg):
+    L, E, seed = reg
+    draft, events, truth = synth.make_region(L, E, seed, swalign, P)
+    pa = PSAlign(); pa.sequence, pa.events, pa.params = draft, events, dict(P)
+    sc = pa.ScoreEvents(); pa.Refine()
+    return pa.sequence, np.array(sc)
+res = psdist.run_regions([(300, 5, 1), (320, 5, 2), (280, 4, 3)], process, max_events=8)
+print(json.dumps({"n": len(res), "lens": [len(r[0]) for r in res], "tmax": psdist.max_over_ranks(2.5), "s0": res[0][1][:5].tolist()}))
+''' % B.ROOT
+    out = subprocess.check_output([sys.executable, "-c", code], timeout=900, stderr=subprocess.STDOUT)
+    r = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
+    assert r["n"] == 3 and all(l > 250 for l in r["lens"]) and r["tmax"] == 2.5 and all(s > 0 for s in r["s0"])
