@@ -45,7 +45,7 @@ int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* sta
             if (stay) stay[to] = rec[at].y;
             // back-pointer codes exist for the forward matrix only (nothing reads the backward ones)
             if (sm && dir == 0) sm[to] = (uint8_t)(flg[at] & 255);
-            if (ss && dir == 0) ss[to] = (uint8_t)(flg[at] >> 8);
+            if (ss && dir == 0) ss[to] = (uint8_t)((flg[at] >> 8) & 7);   // bits 14/15 are the backtrace's sign flags
         }
     }
     return PS_OK;

@@ -129,16 +129,24 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             PS_HIP(hipMemcpyAsync(r_rl.data(), d_rl, r_rl.size() * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
             PS_HIP(hipStreamSynchronize(rt->stream));
             tk.lap("seed D2H");
-            for (size_t q = q0; q < q1; q++) {
+            std::vector<std::vector<double>> lks(ns);
+            auto likes_seed = [&](size_t q) {
                 const std::string& sd = seeds[need[q]];
-                std::vector<double> lk(std::max<size_t>(sd.size(), 4) + 1, 0.0);
+                std::vector<double>& lk = lks[q - q0];
+                lk.assign(std::max<size_t>(sd.size(), 4) + 1, 0.0);
                 for (int e = 0; e < a->E; e++) {
                     const size_t o = (q - q0) * a->ntot + a->off[e];
                     accumulate_likes(r_ra.data() + o, r_rl.data() + o, a->n[e], (int)sstates[q].size(), lk.data());
                 }
                 lk.resize(sd.size());
-                a->seqlikes[sd] = lk;
+            };
+            {
+                std::vector<std::thread> th;
+                for (size_t q = q0 + 1; q < q1; q++) th.emplace_back(likes_seed, q);
+                likes_seed(q0);
+                for (std::thread& x : th) x.join();
             }
+            for (size_t q = q0; q < q1; q++) a->seqlikes[seeds[need[q]]] = std::move(lks[q - q0]);
             q0 = q1;
         }
     } else if (!need.empty()) {

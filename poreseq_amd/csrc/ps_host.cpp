@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <cstdio>
 #include <ctime>
 
@@ -425,8 +426,17 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
     extra = std::max(extra, 0) + 2;
     if (ncolmax > 64 && WS > 511) return fail(PS_ERR_UNSUPPORTED, "edit longer than 58 bases with scoring_width > 511");
     std::vector<int> h_states((size_t)M * ncolmax, -1);
-    for (int i = 0; i < M; i++)
-        if (h_ncol[i] > 0) edited_window(a->bases, muts[i], std::max(muts[i].start - 4, 0), h_ncol[i], h_states.data() + (size_t)i * ncolmax);
+    {
+        auto work = [&](int lo, int hi) {
+            for (int i = lo; i < hi; i++)
+                if (h_ncol[i] > 0) edited_window(a->bases, muts[i], std::max(muts[i].start - 4, 0), h_ncol[i], h_states.data() + (size_t)i * ncolmax);
+        };
+        const int nth = M >= 4096 ? 8 : 1;   // Refine-sized lists: split over a few host threads (disjoint outputs)
+        std::vector<std::thread> th;
+        for (int t = 1; t < nth; t++) th.emplace_back(work, (int)((int64_t)M * t / nth), (int)((int64_t)M * (t + 1) / nth));
+        work(0, (int)((int64_t)M / nth));
+        for (std::thread& x : th) x.join();
+    }
     // distinct r0 = max(start - 3, 1)
     std::vector<int> r0s;
     {
@@ -525,8 +535,19 @@ int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {
     Tick tk("make_mutations");
     const int spacing = 10;
     int nb = 0;
-    std::sort(muts.begin(), muts.end(), by_score_desc);
-    while (!muts.empty() && muts.back().score < 0) muts.pop_back();
+    {
+        // std::sort on indices makes exactly the comparisons (hence the same permutation, ties included) it would
+        // make on the structs themselves, without moving two std::strings per swap
+        std::vector<int> order(muts.size());
+        std::iota(order.begin(), order.end(), 0);
+        const std::vector<Mut>& mref = muts;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return by_score_desc(mref[x], mref[y]); });
+        while (!order.empty() && muts[order.back()].score < 0) order.pop_back();
+        std::vector<Mut> kept;
+        kept.reserve(order.size());
+        for (int k : order) kept.push_back(std::move(muts[k]));
+        muts.swap(kept);
+    }
     if (muts.empty()) { *nbases = 0; return PS_OK; }
     std::vector<Mut> later;
     bool changed = false;

@@ -445,7 +445,9 @@ __global__ __launch_bounds__(256) void k_steps(BatchD b, int ndir) {
                 if (cIGN > nm) { nm = cIGN; sm = M_IGNORE; }
                 if (ns > nm) { nm = ns; sm = M_STAY; }
             }
-            flg[cell] = (unsigned short)(sm | (ss << 8));
+            // bits 14 / 15: main / stay score <= 0 (the backtrace stops there, cpp/Alignment.cpp:542) so that the
+            // walker needs nothing but this word
+            flg[cell] = (unsigned short)(sm | (ss << 8) | (v.x <= 0.0 ? 0x4000u : 0u) | (v.y <= 0.0 ? 0x8000u : 0u));
         }
     }
     if (use_lds) {
@@ -506,59 +508,63 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
 // ------------------------------------------------------------------------------------------------
 // backtrace (cpp/Alignment.cpp:516-624): one wave per job, 16x16 tiles staged in LDS
 // ------------------------------------------------------------------------------------------------
-constexpr int BT = 32;   // tile edge of the backtrace (48 measured slower: 9 loads per thread per tile)
+constexpr int BT = 64;   // tile edge of the backtrace (step words only: 2 bytes per cell, 16 loads per thread in flight)
 
+// The walker navigates on the 16-bit step words alone (codes + "score <= 0" bits written by k_steps), so a
+// tile is 64 x 64 cells = 8 KB of LDS and is reloaded every ~65 hops.  For every recorded level it stores
+// ref_align directly and, in ref_like's slot, the cell it was recorded from as an integer (column << 1 | matrix);
+// k_fill_like then replaces those by the stored scores in parallel.
+// (Measured alternatives that did not pay: prefetching the three possible successor words (tried on both the
+// 18-byte and the 2-byte tile), 48x48 / 96x96 tiles, emitting whole diagonal MATCH runs per iteration.  The walk is
+// ~60 scalar instructions + one LDS round trip per hop.)
 __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
     const JobD& J = b.jobs[blockIdx.x];
     if (b.out[blockIdx.x].inert) return;  // stripe_width == 0: the event is left untouched
     const JobOut O = b.out[blockIdx.x];
     const int tid = threadIdx.x, P = J.P, n0 = J.n0;
     double* __restrict__ ra = J.ra;
-    double* __restrict__ rl = J.rl;
-    for (int t = tid; t < n0; t += 256) { ra[t] = 0.0; rl[t] = 0.0; }
+    long long* __restrict__ rlw = (long long*)J.rl;
+    for (int t = tid; t < n0; t += 256) { ra[t] = 0.0; rlw[t] = 0ll; }
     __syncthreads();
-    const double2* __restrict__ rec = b.rec + J.mat_off[0];
     const unsigned short* __restrict__ flg = b.flg + J.mat_off[0];
-    __shared__ double2 t_rec[BT][BT + 1];
     __shared__ unsigned short t_step[BT][BT + 2];
     __shared__ int s_state[4];
     int i = O.bi, j = O.bj, arr = 0;
     bool done = (i <= 0);
     while (!done) {
         const int ti = i, tj = j;
-        for (int idx = tid; idx < BT * BT; idx += 256) {
-            const int a = idx / BT, c = idx % BT;
-            const int r = ti - a, col = tj - c;
-            double2 v = make_double2(0.0, 0.0); unsigned short st = 0;
-            if (r >= 1 && col >= 1) {
-                const int64_t at = (int64_t)(r + col) * P + slot_of(r, P);
-                v = rec[at]; st = flg[at];
+        {
+            unsigned short tmp[BT * BT / 256];
+#pragma unroll
+            for (int q = 0; q < BT * BT / 256; q++) {   // all loads of a thread in flight before the first LDS store
+                const int idx = tid + 256 * q, a = idx / BT, c = idx % BT;
+                const int r = ti - a, col = tj - c;
+                unsigned short st = 0x4000u | 0x8000u;   // outside the matrix: score 0, the walk stops
+                if (r >= 1 && col >= 1) st = flg[(int64_t)(r + col) * P + slot_of(r, P)];
+                tmp[q] = st;
             }
-            t_rec[a][c] = v; t_step[a][c] = st;
+#pragma unroll
+            for (int q = 0; q < BT * BT / 256; q++) { const int idx = tid + 256 * q; t_step[idx / BT][idx % BT] = tmp[q]; }
         }
         __syncthreads();
         if (tid == 0) {
-            // Measured alternatives that did not pay: prefetching the three possible successor cells (more LDS
-            // reads than they hide), 48x48 tiles (9 loads per thread), and emitting whole diagonal MATCH runs
-            // per iteration (the run lengths cost k_steps as much as the walk saved).
             while (true) {
                 const int a = ti - i, c = tj - j;
                 if (i <= 0) { done = true; break; }
                 if (a >= BT || c >= BT) break;  // left the tile: reload around (i, j)
-                const unsigned stp = t_step[a][c];
-                const double2 v = t_rec[a][c];
-                const unsigned st = arr ? (stp >> 8) : (stp & 255u);
-                const double sc = arr ? v.y : v.x;
-                if (sc <= 0.0) { done = true; break; }
+                const unsigned w = t_step[a][c];
+                const unsigned st = arr ? ((w >> 8) & 7u) : (w & 255u);
+                if (w & (arr ? 0x8000u : 0x4000u)) { done = true; break; }   // score <= 0
+                const long long here = ((long long)j << 1) | arr;
                 if (st == M_SKIP) { j--; }
-                else if (st == M_MATCH) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; j--; }
-                else if (st == M_IGNORE) { ra[i - 1] = -1.0; rl[i - 1] = sc; i--; j--; }
-                else if (st == M_INSERT) { ra[i - 1] = -1.0; rl[i - 1] = sc; i--; }
+                else if (st == M_MATCH) { ra[i - 1] = (double)j; rlw[i - 1] = here; i--; j--; }
+                else if (st == M_IGNORE) { ra[i - 1] = -1.0; rlw[i - 1] = here; i--; j--; }
+                else if (st == M_INSERT) { ra[i - 1] = -1.0; rlw[i - 1] = here; i--; }
                 else if (st == M_STAY) {
-                    if (arr == 1) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
+                    if (arr == 1) { ra[i - 1] = (double)j; rlw[i - 1] = here; i--; }
                     arr = 1 - arr;
                 }
-                else if (st == M_EXTEND) { ra[i - 1] = (double)j; rl[i - 1] = sc; i--; }
+                else if (st == M_EXTEND) { ra[i - 1] = (double)j; rlw[i - 1] = here; i--; }
                 else { done = true; break; }
             }
             s_state[0] = i; s_state[1] = j; s_state[2] = arr; s_state[3] = done ? 1 : 0;
@@ -567,6 +573,19 @@ __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
         i = s_state[0]; j = s_state[1]; arr = s_state[2]; done = s_state[3] != 0;
         __syncthreads();
     }
+}
+
+// ref_like[i-1] = score of the cell level i was recorded from (cpp/Alignment.cpp:610-618); grid (ceil(maxn/256), njobs)
+__global__ __launch_bounds__(256) void k_fill_like(BatchD b) {
+    const JobD& J = b.jobs[blockIdx.y];
+    if (b.out[blockIdx.y].inert) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= J.n0) return;
+    const long long w = ((const long long*)J.rl)[t];
+    if (w == 0) return;   // level not on the path: ref_like stays 0
+    const int i = t + 1, j = (int)(w >> 1);
+    const double2 v = (b.rec + J.mat_off[0])[(int64_t)(i + j) * J.P + slot_of(i, J.P)];
+    J.rl[t] = (w & 1) ? v.y : v.x;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -817,10 +836,14 @@ int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int
     return PS_OK;
 }
 
-int launch_backtrace(Runtime* rt, const BatchD& b, int) {
+int launch_backtrace(Runtime* rt, const BatchD& b, int maxn) {
     if (!b.njobs) return PS_OK;
     hipLaunchKernelGGL(k_backtrace, dim3(b.njobs), dim3(256), 0, rt->stream, b);
     PS_LAUNCH_CHECK();
+    if (maxn > 0) {
+        hipLaunchKernelGGL(k_fill_like, dim3((maxn + 255) / 256, b.njobs), dim3(256), 0, rt->stream, b);
+        PS_LAUNCH_CHECK();
+    }
     return PS_OK;
 }
 
