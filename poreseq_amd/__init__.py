@@ -4,7 +4,7 @@
 `seqtostates`); `poreseq_amd.consensus` reproduces the call schedule of the reference's
 consensus / variant drivers on top of it.
 """
-from .util import RegionInfo, MutationInfo, MutationScore, LoadParams, SaveParams, DEFAULT_PARAMS  # noqa: F401
+from .util import RegionInfo, MutationInfo, MutationScore, LoadParams, SaveParams, VaryParams, DEFAULT_PARAMS  # noqa: F401
 from .events import PSEvent, PSModel  # noqa: F401
 from . import poreseqcpp  # noqa: F401
 from .poreseqcpp import PSAlign, swalign, seqtostates  # noqa: F401

@@ -74,6 +74,31 @@ def variant_region(pa, muts, region_start=0, params=None, out=None):
     return mutscores
 
 
+def train(make_pa, params, refseq, iters=1, reps=10, save=None, paramlists=None):
+    """Transition-parameter search of `poreseq train` (cmdline.py:246-267): each iteration runs the consensus
+    schedule (reps = 10) once per perturbed parameter set and keeps the most accurate one.
+
+    make_pa(params) must return a freshly loaded PSAlign for the training region with the event models'
+    transition probabilities taken from `params` (what LoadAlignedEvents + setparams do in the reference);
+    the 16 replicas are independent region work-items.  `paramlists` (optional) replaces VaryParams, e.g.
+    for reproducible tests.  Returns (best params, best accuracy per iteration).
+    """
+    from .util import VaryParams, SaveParams
+    best_accs = []
+    for it in range(iters):
+        paramlist = paramlists[it] if paramlists is not None else VaryParams(params)
+        accs = []
+        for p in paramlist:
+            pa = make_pa(p)
+            _seq, acc = consensus_region(pa, p, reps=reps, refseq=refseq)
+            accs.append(acc)
+        params = paramlist[int(np.argmax(accs))]
+        if save:
+            SaveParams(save, params)
+        best_accs.append(max(accs))
+    return params, best_accs
+
+
 def split_regions(length, region_length=10000):
     """[(start, end)] region work-items: region_length pieces stepping by region_length - 1000
     (split_fasta.py:94-101; a 35 000-base sequence gives 0:10000, 9000:19000, 18000:28000, 27000:35000)."""

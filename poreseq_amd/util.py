@@ -89,6 +89,20 @@ def LoadParams(filename):
     return params
 
 
+def VaryParams(params):
+    '''16 perturbed copies of `params` for one training iteration: three random *_t / *_c keys each scaled by
+    N(1, 0.15) (poreseq/Params.py:31-60; Python's `random`, unseeded, as the reference).'''
+    import random
+    pnames = [x for x in params.keys() if x[-2:] == '_t' or x[-2:] == '_c']
+    paramlist = []
+    for _ in range(16):
+        newparams = params.copy()
+        for k in random.sample(pnames, 3):
+            newparams[k] *= random.gauss(1.0, 0.15)
+        paramlist.append(newparams)
+    return paramlist
+
+
 def SaveParams(filename, params):
     with open(filename, 'w') as f:
         for p in params:

@@ -85,3 +85,30 @@ def test_split_and_merge_regions():
     s = synth.random_sequence(rng, 5000)
     a, b = s[:3000], s[2000:]
     assert consensus.merge_seqs(a, b, 1000, swalign=B.oracle_swalign) == s
+
+
+def test_train_driver_picks_the_most_accurate_parameter_set():
+    """cmdline.py:246-267 on the oracle backend: 3 fixed parameter sets, the best one must be returned."""
+    import copy
+    from poreseq_amd import synth
+    from poreseq_amd.util import DEFAULT_PARAMS, VaryParams
+    P = dict(DEFAULT_PARAMS, verbose=0)
+    draft, events, truth = synth.make_region(220, 6, 91, B.oracle_swalign, P)
+
+    def make_pa(p):
+        evs = copy.deepcopy(events)
+        for e in evs:
+            e.setparams(p)
+        return B.make_pa(B.OraclePSAlign, draft, evs, p)
+
+    sets = [dict(P), dict(P, skip_t=0.6, skip_c=0.6, stay_t=0.5, stay_c=0.5), dict(P, insert_t=0.3, insert_c=0.3)]
+    B.reset_rand()
+    best, accs = consensus.train(make_pa, P, truth, iters=1, reps=2, paramlists=[sets])
+    B.reset_rand()
+    each = []
+    for p in sets:
+        each.append(consensus.consensus_region(make_pa(p), p, reps=2, refseq=truth)[1])
+    assert best in sets and accs[0] >= max(each) - 1e-9
+    vp = VaryParams(P)
+    assert len(vp) == 16 and all(set(v) == set(P) for v in vp)
+    assert all(sum(v[k] != P[k] for k in P) == 3 for v in vp)      # exactly three transition keys move
