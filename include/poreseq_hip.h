@@ -12,6 +12,11 @@
  * never falls back to a CPU implementation: without a usable HIP device every
  * compute call fails with PS_ERR_NO_DEVICE.
  *
+ * Threading: every host thread that calls into the library gets its own runtime (HIP streams and device
+ * buffer pools), so independent ps_align handles may be driven concurrently from different threads — the
+ * way to keep an MI355X busy with many independent regions.  One handle must not be shared between
+ * threads.  libc rand() (ps_viterbi_mutate) is process-global, as in the reference.
+ *
  * Indices follow the reference: mutation `start` is a 0-based base index,
  * ref_align values are 1-based state indices (0 = unaligned, -1 = inserted
  * level), Smith-Waterman index lists are 1-based with 0 = gap.

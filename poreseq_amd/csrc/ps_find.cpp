@@ -13,6 +13,13 @@
 
 namespace ps {
 
+// cap on the DP-matrix bytes of one seed batch (PORESEQ_MAX_BATCH_GB, default 48): lower it when several host
+// threads share one GPU
+static double max_batch_bytes() {
+    static const double v = [] { const char* e = getenv("PORESEQ_MAX_BATCH_GB"); const double g = e ? atof(e) : 48.0; return (g > 0 ? g : 48.0) * 1e9; }();
+    return v;
+}
+
 static void fillinds(SwResult& al) {  // cpp/swlib.cpp:342-365
     if (al.a.empty()) return;
     int i1 = al.a[0], i2 = al.b[0];
@@ -71,7 +78,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             while (q1 < need.size()) {
                 double add = 0;
                 for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + sstates[q1].size() + 1) * P * 26.0;
-                if (q1 > q0 && bytes + add > 48e9) break;
+                if (q1 > q0 && bytes + add > max_batch_bytes()) break;
                 bytes += add; q1++;
             }
             const size_t ns = q1 - q0;

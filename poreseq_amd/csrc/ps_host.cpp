@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <mutex>
 #include <thread>
 #include <cstdio>
 #include <ctime>
@@ -53,10 +54,32 @@ int HBuf::ensure(size_t bytes) {
     return PS_OK;
 }
 
+// One runtime (HIP streams + grow-only device pools) per host thread that is inside the library: independent
+// PSAlign pipelines driven from different threads run concurrently on the GPU — a single region keeps at most a
+// few dozen of the 256 CUs busy, and regions are independent work-items.  Runtimes live in a process-wide
+// free-list: a thread adopts one on its first call and hands it back when it exits, so short-lived worker
+// threads reuse the pools instead of re-allocating (or leaking) them.
+namespace {
+struct RtSlot { Runtime R; int state = 0; std::string why; };   // state: 0 untried, 1 ok, -1 failed
+std::mutex g_rt_mu;
+std::vector<RtSlot*> g_rt_free;
+struct RtHolder {
+    RtSlot* s = nullptr;
+    ~RtHolder() { if (s) { std::lock_guard<std::mutex> lk(g_rt_mu); g_rt_free.push_back(s); } }
+};
+thread_local RtHolder t_rt;
+}  // namespace
+
 int runtime(Runtime** out) {
-    static Runtime R;
-    static int state = 0;  // 0 untried, 1 ok, -1 failed
-    static std::string why;
+    if (!t_rt.s) {
+        std::lock_guard<std::mutex> lk(g_rt_mu);
+        if (!g_rt_free.empty()) { t_rt.s = g_rt_free.back(); g_rt_free.pop_back(); }
+        else t_rt.s = new RtSlot();
+        if (t_rt.s->state == 1) (void)hipSetDevice(t_rt.s->R.device);   // the current device is per-thread state
+    }
+    Runtime& R = t_rt.s->R;
+    int& state = t_rt.s->state;
+    std::string& why = t_rt.s->why;
     if (state == 0) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);

@@ -79,3 +79,22 @@ def test_unsupported_and_limits_fail_loudly():
     a = B.make_pa(PSAlign, draft, copy.deepcopy(events), z).ScorePoints()
     b = B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), z).ScorePoints()
     assert np.array_equal(np.array([m.score for m in a]), np.array([m.score for m in b]))
+
+
+def test_concurrent_regions_from_threads_match_oracle():
+    """Per-thread runtimes: two regions scored from two host threads at once give the same bits as alone."""
+    import threading
+    regs = [synth.make_region(400, 6, 81 + k, B.oracle_swalign, P0) for k in range(3)]
+    want = [np.array([m.score for m in B.make_pa(B.OraclePSAlign, d, copy.deepcopy(e), P0).ScorePoints()]) for d, e, _ in regs]
+    got = [None] * 3
+
+    def work(k):
+        for _ in range(3):
+            d, e, _t = regs[k]
+            got[k] = np.array([m.score for m in B.make_pa(PSAlign, d, copy.deepcopy(e), P0).ScorePoints()])
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(3):
+        assert np.array_equal(got[k], want[k])
