@@ -75,7 +75,7 @@ def simulate_event(rng, states, model, p_stay=0.05, p_skip=0.10):
     return np.array(mean), np.array(stdv), np.array(ral, dtype=np.float64)
 
 
-def make_region(length, n_events, seed, swalign, params=None, draft_error=0.04, read_error=0.05):
+def make_region(length, n_events, seed, swalign, params=None, draft_error=0.04, read_error=0.05, truth=None):
     """Build (draft sequence, events, truth) for one region.
 
     `swalign(seq1, seq2) -> (accuracy, pairs)` re-maps the events' truth alignment onto the
@@ -87,7 +87,8 @@ def make_region(length, n_events, seed, swalign, params=None, draft_error=0.04, 
     root = np.random.SeedSequence(seed)
     kids = root.spawn(n_events + 2)
     rng0 = np.random.default_rng(kids[0])
-    truth = random_sequence(rng0, length)
+    if truth is None:
+        truth = random_sequence(rng0, length)   # else: a slice of a longer genome (overlapping region work-items)
     st = states_of(truth)
     events = []
     for e in range(n_events):
