@@ -15,7 +15,7 @@
  * Threading: every host thread that calls into the library gets its own runtime (HIP streams and device
  * buffer pools), so independent ps_align handles may be driven concurrently from different threads — the
  * way to keep an MI355X busy with many independent regions.  One handle must not be shared between
- * threads.  libc rand() (ps_viterbi_mutate) is process-global, as in the reference.
+ * threads.  The uniform deviates of ps_viterbi_mutate come from a per-thread generator (see ps_srand).
  *
  * Indices follow the reference: mutation `start` is a 0-based base index,
  * ref_align values are 1-based state indices (0 = unaligned, -1 = inserted
@@ -118,8 +118,16 @@ int ps_score_mutations(ps_align* a, const ps_muts* muts, ps_muts** out_scored);
 /* MakeMutations (cpp/MakeMutations.cpp:74-146): greedy application, returns mutated-base count. */
 int ps_make_mutations(ps_align* a, const ps_muts* scored, int32_t* n_bases);
 
-/* ViterbiMutate (cpp/Viterbi.h:67-68, cpp/Viterbi.cpp:239-426).  Uses libc rand() for the
- * nkeep > 0 stochastic back-traces exactly as the reference does (never seeded). */
+/* ViterbiMutate (cpp/Viterbi.h:67-68, cpp/Viterbi.cpp:239-426).  The nkeep > 0 stochastic back-traces draw
+ * rand() / (RAND_MAX + 1.0) in the reference's call order (cpp/Viterbi.cpp:108).  The reference never seeds
+ * libc rand() and runs one process per region, so every region sees the generator of a fresh process.  The
+ * HIP library keeps that contract per host thread: each thread owns a glibc random_r() state (the TYPE_3
+ * additive-feedback generator rand() itself uses), initially seeded with 1 like an unseeded process, without
+ * the process-wide lock behind rand() that serialises concurrent regions.  ps_srand re-seeds the calling
+ * thread's generator (srand(seed) in the oracle / reference builds of this ABI). */
+int ps_srand(uint32_t seed);
+/* The next n deviates rand() / (RAND_MAX + 1.0) of the calling thread's generator (consumes them). */
+int ps_rand_draw(int64_t n, double* out);
 int ps_viterbi_mutate(ps_align* a, int32_t nkeep, double skip_prob, double stay_prob,
                       double mut_min, double mut_max, int32_t verbose, ps_seqs** out);
 

@@ -61,6 +61,8 @@ SYMBOLS = {
     "ps_make_mutations": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p]),
     "ps_viterbi_mutate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ps_srand": (C.c_int, [C.c_uint32]),
+    "ps_rand_draw": (C.c_int, [C.c_int64, c_dp]),
     "ps_swfull": (C.c_int, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, c_i32p, c_dp, c_i32p,
                             c_i32p, C.c_int64, c_i64p]),
     "ps_seq_to_states": (C.c_int, [C.c_char_p, C.c_int64, c_i32p, c_i64p]),
@@ -248,6 +250,14 @@ class CApi:
             return self.seqs_export(out)
         finally:
             self.lib.ps_seqs_destroy(out)
+
+    def srand(self, seed):
+        self.check(self.lib.ps_srand(int(seed)))
+
+    def rand_draw(self, n):
+        out = np.zeros(int(n), dtype=np.float64)
+        self.check(self.lib.ps_rand_draw(int(n), _dp(out)))
+        return out
 
     def swfull(self, s1, s2):
         b1, b2 = s1.encode("ascii"), s2.encode("ascii")

@@ -186,6 +186,13 @@ int ps_debug_fill(ps_align* a, int32_t e, int32_t dir, double* main, double* sta
     return debug_fill(rt, &a->a, e, dir, main, stay, sm, ss);
 }
 
+int ps_srand(uint32_t seed) { rand_seed(seed); return PS_OK; }
+int ps_rand_draw(int64_t n, double* out) {
+    if (n < 0 || (n && !out)) return fail(PS_ERR_BAD_ARG, "ps_rand_draw");
+    for (int64_t k = 0; k < n; k++) out[k] = rand_next() / (double(RAND_MAX) + 1);
+    return PS_OK;
+}
+
 int ps_prof_enable(int32_t on) {
     NEED_RT();
     rt->prof_on = on != 0;

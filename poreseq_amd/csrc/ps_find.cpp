@@ -83,10 +83,13 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             }
             const size_t ns = q1 - q0;
             // remapped ref_align of every (seed, event) job, cpp/EventUtil.cpp:22-51
-            std::vector<double> h_ra((size_t)ns * a->ntot);
+            const size_t nref = (size_t)ns * a->ntot;
+            const size_t stage_mark = rt->stage.mark();
+            double* h_ra = (double*)rt->stage.alloc(std::max<size_t>(nref, 1) * sizeof(double));   // pinned: plain enqueue below
+            if (!h_ra) return fail(PS_ERR_NOMEM, "hipHostMalloc (staging arena)");
             auto remap_seed = [&](size_t q) {
                 const SwResult& al = als[need[q]];
-                double* dst = h_ra.data() + (q - q0) * a->ntot;
+                double* dst = h_ra + (q - q0) * a->ntot;
                 for (int64_t t = 0; t < a->ntot; t++) {
                     const int ra = (int)a->h_ra[t];
                     double v = 0.0;
@@ -109,7 +112,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             double* d_ra = rb.as<double>();
             double* d_rl = d_ra + ns * a->ntot;
             double* d_ri = d_rl + ns * a->ntot;
-            PS_HIP(hipMemcpyAsync(d_ra, h_ra.data(), h_ra.size() * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+            if (nref) PS_HIP(hipMemcpyAsync(d_ra, h_ra, nref * sizeof(double), hipMemcpyHostToDevice, rt->stream));
             PS_HIP(hipMemsetAsync(d_rl, 0, ns * a->ntot * sizeof(double), rt->stream));
             std::vector<JobSpec> specs;
             for (size_t q = q0; q < q1; q++)
@@ -131,9 +134,9 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             PS_TRY(realign(rt, a, b, 0));
             PS_HIP(hipStreamSynchronize(rt->stream));
             tk.lap("seed realign");
-            std::vector<double> r_ra(ns * a->ntot), r_rl(ns * a->ntot);
-            PS_HIP(hipMemcpyAsync(r_ra.data(), d_ra, r_ra.size() * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
-            PS_HIP(hipMemcpyAsync(r_rl.data(), d_rl, r_rl.size() * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
+            double *r_ra = nullptr, *r_rl = nullptr;
+            PS_TRY(rt->down(&r_ra, d_ra, nref));
+            PS_TRY(rt->down(&r_rl, d_rl, nref));
             PS_HIP(hipStreamSynchronize(rt->stream));
             tk.lap("seed D2H");
             std::vector<std::vector<double>> lks(ns);
@@ -143,7 +146,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
                 lk.assign(std::max<size_t>(sd.size(), 4) + 1, 0.0);
                 for (int e = 0; e < a->E; e++) {
                     const size_t o = (q - q0) * a->ntot + a->off[e];
-                    accumulate_likes(r_ra.data() + o, r_rl.data() + o, a->n[e], (int)sstates[q].size(), lk.data());
+                    accumulate_likes(r_ra + o, r_rl + o, a->n[e], (int)sstates[q].size(), lk.data());
                 }
                 lk.resize(sd.size());
             };
@@ -154,6 +157,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
                 for (std::thread& x : th) x.join();
             }
             for (size_t q = q0; q < q1; q++) a->seqlikes[seeds[need[q]]] = std::move(lks[q - q0]);
+            rt->stage.release(stage_mark);   // the stream is idle: this batch's staging memory can be reused
             q0 = q1;
         }
     } else if (!need.empty()) {
@@ -275,6 +279,28 @@ static std::string path_to_bases(const std::vector<int>& st) {
     return s;
 }
 
+// rand() of a fresh process, per host thread (include/poreseq_hip.h, ps_srand): glibc's reentrant random_r() on
+// a 128-byte TYPE_3 state is the generator behind rand() minus the process-wide lock.
+namespace {
+struct RandState {
+    random_data rd;
+    char st[128];
+    bool init = false;
+};
+thread_local RandState t_rand;
+}  // namespace
+void rand_seed(unsigned seed) {
+    memset(&t_rand.rd, 0, sizeof(t_rand.rd));
+    initstate_r(seed, t_rand.st, sizeof(t_rand.st), &t_rand.rd);
+    t_rand.init = true;
+}
+int rand_next() {
+    if (!t_rand.init) rand_seed(1);
+    int32_t r = 0;
+    random_r(&t_rand.rd, &r);
+    return (int)r;
+}
+
 int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, double mmin, double mmax,
                    std::vector<std::string>* out) {
     out->clear();
@@ -282,10 +308,10 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
     const int E = a->E;
     // host mirrors of ref_align / ref_index / refstart / refend
     PS_TRY(a->refs_to_host(rt));
-    std::vector<double> h_ri(std::max<int64_t>(a->ntot, 1));
-    std::vector<JobOut> info(E);
-    PS_HIP(hipMemcpyAsync(h_ri.data(), a->d_ri, a->ntot * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
-    PS_HIP(hipMemcpyAsync(info.data(), a->d_out, E * sizeof(JobOut), hipMemcpyDeviceToHost, rt->stream));
+    double* h_ri = nullptr;
+    JobOut* info = nullptr;
+    PS_TRY(rt->down(&h_ri, a->d_ri, (size_t)a->ntot));
+    PS_TRY(rt->down(&info, a->d_out, (size_t)E));
     PS_HIP(hipStreamSynchronize(rt->stream));
     tk.lap("refs D2H");
     // first level whose ref_index equals an integer position (std::find in getrefstates, cpp/EventData.h:192),
@@ -295,7 +321,7 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
     int maxpos = 0;
     for (int e = 0; e < E; e++) {
         if (!info[e].has_index) continue;
-        const double* ri = h_ri.data() + a->off[e];
+        const double* ri = h_ri + a->off[e];
         for (int t = 0; t < a->n[e]; t++) {
             const double v = ri[t];
             if (v >= 0.0 && v < 1e9 && v == std::floor(v)) maxpos = std::max(maxpos, (int)v);
@@ -305,7 +331,7 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
     for (int e = 0; e < E; e++) {
         if (!info[e].has_index) continue;  // empty ref_index: getrefstates finds nothing
         first[e].assign((size_t)maxpos + 1, -1);
-        const double* ri = h_ri.data() + a->off[e];
+        const double* ri = h_ri + a->off[e];
         for (int t = 0; t < a->n[e]; t++) {
             const double v = ri[t];
             if (v >= 0.0 && v <= (double)maxpos && v == std::floor(v)) {
@@ -356,7 +382,7 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
     if (T == 0) return PS_OK;
     // uniform deviates in the reference's call order: for each kept path, one per back-step (cpp/Viterbi.cpp:108)
     std::vector<double> rnd((size_t)nkeep * T);
-    for (size_t k = 0; k < rnd.size(); k++) rnd[k] = rand() / (double(RAND_MAX) + 1);
+    for (size_t k = 0; k < rnd.size(); k++) rnd[k] = rand_next() / (double(RAND_MAX) + 1);
     tk.lap("rand");
     std::vector<std::vector<int>> paths;
     PS_TRY(viterbi_device(rt, E, T, obsin.data(), a->d_model, nkeep, skip, stay, mmin, mmax, rnd.data(), &paths));

@@ -54,6 +54,54 @@ int HBuf::ensure(size_t bytes) {
     return PS_OK;
 }
 
+void* Stage::alloc(size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    if (chunks.empty() || used + bytes > chunks.back().cap) {
+        size_t want = std::max<size_t>(bytes, chunks.empty() ? (size_t)4 << 20 : 2 * chunks.back().cap);
+        void* p = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            want = bytes;
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        }
+        chunks.push_back({(char*)p, want});
+        used = 0;
+    }
+    void* r = chunks.back().p + used;
+    used += bytes;
+    dirty = true;
+    return r;
+}
+
+int Stage::reset() {
+    if (chunks.size() > 1) {   // grew during the last call: one chunk of the combined size from now on
+        size_t tot = 0;
+        for (Chunk& c : chunks) { tot += c.cap; PS_HIP(hipHostFree(c.p)); }
+        chunks.clear();
+        void* p = nullptr;
+        if (hipHostMalloc(&p, tot, hipHostMallocDefault) == hipSuccess) chunks.push_back({(char*)p, tot});
+    }
+    used = 0;
+    dirty = false;
+    return PS_OK;
+}
+
+int Runtime::up(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return PS_OK;
+    void* h = stage.alloc(bytes);
+    if (!h) return fail(PS_ERR_NOMEM, "hipHostMalloc (staging arena)");
+    memcpy(h, src, bytes);
+    PS_HIP(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, st ? st : stream));
+    return PS_OK;
+}
+
+int Runtime::down(void** hptr, const void* src, size_t bytes, hipStream_t st) {
+    void* h = stage.alloc(bytes);
+    if (!h) return fail(PS_ERR_NOMEM, "hipHostMalloc (staging arena)");
+    *hptr = h;
+    if (bytes) PS_HIP(hipMemcpyAsync(h, src, bytes, hipMemcpyDeviceToHost, st ? st : stream));
+    return PS_OK;
+}
+
 // One runtime (HIP streams + grow-only device pools) per host thread that is inside the library: independent
 // PSAlign pipelines driven from different threads run concurrently on the GPU — a single region keeps at most a
 // few dozen of the 256 CUs busy, and regions are independent work-items.  Runtimes live in a process-wide
@@ -110,6 +158,11 @@ int runtime(Runtime** out) {
         }
     }
     if (state < 0) return fail(PS_ERR_NO_DEVICE, why);
+    if (R.stage.dirty) {   // a new API call: nothing staged by the previous one may still be in flight
+        PS_HIP(hipStreamSynchronize(R.stream));
+        PS_HIP(hipStreamSynchronize(R.stream2));
+        PS_TRY(R.stage.reset());
+    }
     *out = &R;
     return PS_OK;
 }
@@ -196,10 +249,8 @@ int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int n
     PS_TRY(rt->buf("lo").ensure(std::max<int64_t>(lo_tot, 1) * sizeof(int)));
     PS_TRY(rt->buf("cmax").ensure(std::max<int64_t>(col_tot, 1) * sizeof(double)));
     PS_TRY(rt->buf("pm").ensure(std::max<int64_t>(col_tot, 1) * sizeof(double)));
-    PS_HIP(hipMemcpyAsync(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD), hipMemcpyHostToDevice, rt->stream));
-    if (!h_states.empty())
-        PS_HIP(hipMemcpyAsync(rt->buf("states").p, h_states.data(), h_states.size() * sizeof(int), hipMemcpyHostToDevice, rt->stream));
-    PS_HIP(hipStreamSynchronize(rt->stream));  // the staging vectors die with this scope
+    PS_TRY(rt->up(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD)));
+    PS_TRY(rt->up(rt->buf("states").p, h_states.data(), h_states.size() * sizeof(int)));
     d.jobs = rt->buf("jobs").as<JobD>();
     d.njobs = (int)jobs.size();
     d.mean = a->d_mean; d.stdv = a->d_stdv; d.logstdv = a->d_lsd; d.model = a->d_model; d.trans = a->d_trans;
@@ -215,6 +266,7 @@ int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int n
 // second phase: the anti-diagonal footprint of every band is known, size the skewed matrices
 int Batch::place(Runtime* rt, int P_) {
     P = std::min(Pmax, std::max(64, ((P_ + 63) / 64) * 64));
+    if (const char* fp = getenv("PORESEQ_DEBUG_MIN_P")) P = std::min(Pmax, std::max(P, atoi(fp)));  // experiments only
     int64_t mat_tot = 0;
     for (JobD& j : jobs) {
         j.P = P;
@@ -227,8 +279,7 @@ int Batch::place(Runtime* rt, int P_) {
     PS_TRY(rt->buf("flg").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short)));
     PS_TRY(rt->buf("dummy").ensure(jobs.size() * ndir * 1024 * sizeof(double2)));
     d.dummy = rt->buf("dummy").as<double2>();
-    PS_HIP(hipMemcpyAsync(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD), hipMemcpyHostToDevice, rt->stream));
-    PS_HIP(hipStreamSynchronize(rt->stream));
+    PS_TRY(rt->up(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD)));
     d.rec = rt->buf("rec").as<double2>(); d.em = rt->buf("em").as<double>(); d.flg = rt->buf("flg").as<unsigned short>();
     return PS_OK;
 }
@@ -329,9 +380,12 @@ int Align::base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra, bool matric
 
 int Align::refs_to_host(Runtime* rt) {
     if (host_refs_valid || !ntot) { host_refs_valid = true; return PS_OK; }
-    PS_HIP(hipMemcpyAsync(h_ra.data(), d_ra, ntot * 8, hipMemcpyDeviceToHost, rt->stream));
-    PS_HIP(hipMemcpyAsync(h_rl.data(), d_rl, ntot * 8, hipMemcpyDeviceToHost, rt->stream));
+    double *pa = nullptr, *pl = nullptr;
+    PS_TRY(rt->down(&pa, d_ra, (size_t)ntot));
+    PS_TRY(rt->down(&pl, d_rl, (size_t)ntot));
     PS_HIP(hipStreamSynchronize(rt->stream));
+    memcpy(h_ra.data(), pa, ntot * 8);
+    memcpy(h_rl.data(), pl, ntot * 8);
     host_refs_valid = true;
     return PS_OK;
 }
@@ -344,11 +398,11 @@ int realign(Runtime* rt, Align* a, Batch& b, int lb_extra_ready) {
     PS_TRY(launch_begin(rt, b.d));
     PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
     PS_TRY(launch_lo(rt, b.d, b.ndir, b.maxS));
-    std::vector<JobOut> o(b.d.njobs);
-    PS_HIP(hipMemcpyAsync(o.data(), b.d.out, o.size() * sizeof(JobOut), hipMemcpyDeviceToHost, rt->stream));
+    JobOut* o = nullptr;
+    PS_TRY(rt->down(&o, b.d.out, (size_t)b.d.njobs));
     PS_HIP(hipStreamSynchronize(rt->stream));
     int w = 1;
-    for (const JobOut& x : o) w = std::max(w, x.maxw);
+    for (int k = 0; k < b.d.njobs; k++) w = std::max(w, o[k].maxw);
     PS_TRY(b.place(rt, w));
     if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes(a);
     PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P, b.ncols));
@@ -364,8 +418,8 @@ int score_alignments(Runtime* rt, Align* a, double* scores, double* likes) {
     PS_TRY(a->base_batch(rt, &b, 1, 0));
     PS_TRY(realign(rt, a, b, 0));
     a->host_refs_valid = false;
-    std::vector<JobOut> out(a->E);
-    PS_HIP(hipMemcpyAsync(out.data(), a->d_out, a->E * sizeof(JobOut), hipMemcpyDeviceToHost, rt->stream));
+    JobOut* out = nullptr;
+    PS_TRY(rt->down(&out, a->d_out, (size_t)a->E));
     PS_HIP(hipStreamSynchronize(rt->stream));
     for (int e = 0; e < a->E; e++) scores[e] = std::max(out[e].best, 0.0);  // Alignment::getMax, cpp/Alignment.h:127-130
     if (likes) {
@@ -497,7 +551,7 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
     sa.m_skip = push(h_skip); sa.m_oldidx = push(h_oldidx); sa.m_states = push(h_states); sa.r0 = push(r0s);
     const int* cls_items[4]; int cls_count[4];
     for (int k = 0; k < 4; k++) { cls_items[k] = push(cls[k]); cls_count[k] = (int)cls[k].size(); }
-    if (!stage.empty()) PS_HIP(hipMemcpyAsync(dp, stage.data(), stage.size() * sizeof(int), hipMemcpyHostToDevice, rt->stream));
+    PS_TRY(rt->up(dp, stage.data(), stage.size() * sizeof(int)));
     DBuf& db = rt->buf("mutdbl");
     const size_t dbl = (size_t)a->E * std::max(nr0, 1) + (size_t)a->E * std::max(M, 1) + std::max(M, 1);
     PS_TRY(db.ensure(dbl * sizeof(double)));
@@ -519,8 +573,8 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
             rt->prof["score"].bytes += t * a->E;
         }
         PS_TRY(launch_score(rt, b.d, sa, cls_items, cls_count));
-        std::vector<double> sc(M);
-        PS_HIP(hipMemcpyAsync(sc.data(), sa.score, M * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
+        double* sc = nullptr;
+        PS_TRY(rt->down(&sc, sa.score, (size_t)M));
         PS_HIP(hipStreamSynchronize(rt->stream));
         for (int i = 0; i < M; i++) (*out)[i].score = sc[i];
         tk.lap("score edits");

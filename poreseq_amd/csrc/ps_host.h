@@ -17,6 +17,9 @@ struct Tick {
 
 struct Align;
 
+void rand_seed(unsigned seed);   // per-thread generator of ViterbiMutate's deviates (ps_find.cpp)
+int rand_next();
+
 struct JobSpec {
     int ev = 0;
     const std::vector<int>* states = nullptr;

@@ -56,6 +56,23 @@ struct HBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Pinned staging arena: host<->device copies of per-call tables go through it so that hipMemcpyAsync is a
+// plain enqueue (a pageable source makes the runtime stage the copy itself and block the calling thread, which
+// also serialises concurrent host threads).  Memory handed out stays valid until reset(); the arena is reset at
+// the next API entry of the owning thread, after its streams have drained.
+struct Stage {
+    struct Chunk { char* p; size_t cap; };
+    std::vector<Chunk> chunks;
+    size_t used = 0;          // bytes used in the last chunk
+    bool dirty = false;
+    void* alloc(size_t bytes);   // 256-byte aligned, nullptr when pinned memory cannot be had
+    int reset();
+    // scoped reuse inside one API call: everything allocated after mark() is handed back by release(); the caller
+    // guarantees that no copy touching that memory is still in flight
+    size_t mark() const { return chunks.size() <= 1 ? used : (size_t)-1; }
+    void release(size_t m) { if (m != (size_t)-1 && chunks.size() <= 1) used = m; }
+};
+
 struct Prof { double ms = 0; int64_t launches = 0; double bytes = 0; };
 
 struct Runtime {
@@ -70,6 +87,12 @@ struct Runtime {
     std::map<std::string, Prof> prof;
     bool prof_on = false;
     DBuf& buf(const std::string& name) { return pool[name]; }
+    Stage stage;
+    // enqueue host -> device through the arena (the source may die as soon as this returns)
+    int up(void* dst, const void* src, size_t bytes, hipStream_t st = nullptr);
+    // enqueue device -> host into arena memory; *hptr is readable after the stream has been synchronised
+    int down(void** hptr, const void* src, size_t bytes, hipStream_t st = nullptr);
+    template <class T> int down(T** hptr, const void* src, size_t count) { return down((void**)hptr, src, count * sizeof(T)); }
 };
 int runtime(Runtime** out);  // PS_ERR_NO_DEVICE when no usable GPU; never falls back
 

@@ -508,15 +508,36 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
 // ------------------------------------------------------------------------------------------------
 // backtrace (cpp/Alignment.cpp:516-624): one wave per job, 16x16 tiles staged in LDS
 // ------------------------------------------------------------------------------------------------
-constexpr int BT = 64;   // tile edge of the backtrace (step words only: 2 bytes per cell, 16 loads per thread in flight)
+constexpr int BT = 64;   // tile edge of the backtrace (step words only: 2 bytes per cell)
+constexpr int BTM = 8;   // the tile prefetched during a walk overlaps the current one by this many rows / columns
+
+// cooperative load of the BT x BT step-word tile whose corner (largest row / column) is (ti, tj); NT threads, t in [0, NT)
+template <int NT>
+__device__ __forceinline__ void bt_load(unsigned short (*__restrict__ dst)[BT + 2], const unsigned short* __restrict__ flg,
+                                        const int P, const int ti, const int tj, const int t) {
+    constexpr int NQ = (BT * BT + NT - 1) / NT;
+    const int sti = __builtin_amdgcn_readfirstlane(ti > 0 ? ti % P : 0);
+    unsigned short tmp[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {   // all loads of a thread in flight before the first LDS store
+        const int idx = min(t + NT * q, BT * BT - 1), a = idx / BT, c = idx % BT;
+        const int r = ti - a, col = tj - c;
+        int slot = sti - a;          // (ti - a) mod P, a < BT <= P
+        if (slot < 0) slot += P;
+        unsigned short st = 0x4000u | 0x8000u;   // outside the matrix: score 0, the walk stops
+        if (r >= 1 && col >= 1) st = flg[(int64_t)(r + col) * P + slot];
+        tmp[q] = st;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { const int idx = t + NT * q; if (idx < BT * BT) dst[idx / BT][idx % BT] = tmp[q]; }
+}
 
 // The walker navigates on the 16-bit step words alone (codes + "score <= 0" bits written by k_steps), so a
-// tile is 64 x 64 cells = 8 KB of LDS and is reloaded every ~65 hops.  For every recorded level it stores
-// ref_align directly and, in ref_like's slot, the cell it was recorded from as an integer (column << 1 | matrix);
-// k_fill_like then replaces those by the stored scores in parallel.
-// (Measured alternatives that did not pay: prefetching the three possible successor words (tried on both the
-// 18-byte and the 2-byte tile), 48x48 / 96x96 tiles, emitting whole diagonal MATCH runs per iteration.  The walk is
-// ~60 scalar instructions + one LDS round trip per hop.)
+// tile is 64 x 64 cells = 8 KB of LDS.  Wave 0 walks the current tile while waves 1-3 fetch the tile the path
+// is expected to enter next (same diagonal, BTM cells of overlap to absorb drift) into the other LDS buffer; when
+// the walk leaves the current tile inside the prefetched one no load is waited for.  For every recorded level
+// the walker stores ref_align directly and, in ref_like's slot, the cell it was recorded from as an integer
+// (column << 1 | matrix); k_fill_like then replaces those by the stored scores in parallel.
 __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
     const JobD& J = b.jobs[blockIdx.x];
     if (b.out[blockIdx.x].inert) return;  // stripe_width == 0: the event is left untouched
@@ -527,51 +548,72 @@ __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
     for (int t = tid; t < n0; t += 256) { ra[t] = 0.0; rlw[t] = 0ll; }
     __syncthreads();
     const unsigned short* __restrict__ flg = b.flg + J.mat_off[0];
-    __shared__ unsigned short t_step[BT][BT + 2];
-    __shared__ int s_state[4];
+    __shared__ unsigned short t_buf[2][BT][BT + 2];
+    __shared__ int s_state[2][4];
     int i = O.bi, j = O.bj, arr = 0;
     bool done = (i <= 0);
+    int cur = 0, ti = 0, tj = 0, it = 0;
+    bool need = true;
     while (!done) {
-        const int ti = i, tj = j;
-        {
-            unsigned short tmp[BT * BT / 256];
-#pragma unroll
-            for (int q = 0; q < BT * BT / 256; q++) {   // all loads of a thread in flight before the first LDS store
-                const int idx = tid + 256 * q, a = idx / BT, c = idx % BT;
-                const int r = ti - a, col = tj - c;
-                unsigned short st = 0x4000u | 0x8000u;   // outside the matrix: score 0, the walk stops
-                if (r >= 1 && col >= 1) st = flg[(int64_t)(r + col) * P + slot_of(r, P)];
-                tmp[q] = st;
-            }
-#pragma unroll
-            for (int q = 0; q < BT * BT / 256; q++) { const int idx = tid + 256 * q; t_step[idx / BT][idx % BT] = tmp[q]; }
+        if (need) {
+            ti = i; tj = j;
+            bt_load<256>(t_buf[cur], flg, P, ti, tj, tid);
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid == 0) {
+        const int pi = ti - (BT - BTM), pj = tj - (BT - BTM);
+        unsigned short (*t_step)[BT + 2] = t_buf[cur];
+        if (tid >= 64) bt_load<192>(t_buf[cur ^ 1], flg, P, pi, pj, tid - 64);
+        if (tid < 64) {
+            // wave 0 walks; (i, j, arr) are wave-uniform.  Lane l looks l cells ahead on the diagonal, so a run of
+            // MATCH steps (the common case) is emitted by one LDS read + one ballot with coalesced stores; the
+            // first non-MATCH cell after the run is stepped from the word its lane already holds.
+            const int l = tid;
             while (true) {
-                const int a = ti - i, c = tj - j;
+                i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
+                arr = __builtin_amdgcn_readfirstlane(arr);
                 if (i <= 0) { done = true; break; }
+                const int a = ti - i, c = tj - j;
                 if (a >= BT || c >= BT) break;  // left the tile: reload around (i, j)
-                const unsigned w = t_step[a][c];
-                const unsigned st = arr ? ((w >> 8) & 7u) : (w & 255u);
-                if (w & (arr ? 0x8000u : 0x4000u)) { done = true; break; }   // score <= 0
+                const int aa = a + l, cc = c + l;
+                unsigned w = 0xC000u;
+                if (aa < BT && cc < BT) w = t_step[aa][cc];
+                int run = 0;
+                if (arr == 0) {
+                    const unsigned long long mm = __ballot((w & 0x40ffu) == M_MATCH);   // main cell, score > 0, MATCH
+                    run = __builtin_amdgcn_readfirstlane(mm == ~0ull ? 64 : (int)__builtin_ctzll(~mm));
+                    if (l < run) { ra[i - 1 - l] = (double)(j - l); rlw[i - 1 - l] = (long long)(j - l) << 1; }
+                    i -= run; j -= run;
+                    if (run == 64 || a + run >= BT || c + run >= BT) continue;
+                    if (i <= 0) { done = true; break; }
+                }
+                const unsigned wr = __builtin_amdgcn_readlane(w, run);
+                const unsigned st = arr ? ((wr >> 8) & 7u) : (wr & 255u);
+                if (wr & (arr ? 0x8000u : 0x4000u)) { done = true; break; }   // score <= 0
                 const long long here = ((long long)j << 1) | arr;
-                if (st == M_SKIP) { j--; }
-                else if (st == M_MATCH) { ra[i - 1] = (double)j; rlw[i - 1] = here; i--; j--; }
-                else if (st == M_IGNORE) { ra[i - 1] = -1.0; rlw[i - 1] = here; i--; j--; }
-                else if (st == M_INSERT) { ra[i - 1] = -1.0; rlw[i - 1] = here; i--; }
+                double rav = 0.0;
+                int rec = 0, di = 0, dj = 0;
+                if (st == M_SKIP) { dj = 1; }
+                else if (st == M_MATCH) { rav = (double)j; rec = 1; di = 1; dj = 1; }
+                else if (st == M_IGNORE) { rav = -1.0; rec = 1; di = 1; dj = 1; }
+                else if (st == M_INSERT) { rav = -1.0; rec = 1; di = 1; }
                 else if (st == M_STAY) {
-                    if (arr == 1) { ra[i - 1] = (double)j; rlw[i - 1] = here; i--; }
+                    if (arr == 1) { rav = (double)j; rec = 1; di = 1; }
                     arr = 1 - arr;
                 }
-                else if (st == M_EXTEND) { ra[i - 1] = (double)j; rlw[i - 1] = here; i--; }
+                else if (st == M_EXTEND) { rav = (double)j; rec = 1; di = 1; }
                 else { done = true; break; }
+                if (rec && l == 0) { ra[i - 1] = rav; rlw[i - 1] = here; }
+                i -= di; j -= dj;
             }
-            s_state[0] = i; s_state[1] = j; s_state[2] = arr; s_state[3] = done ? 1 : 0;
+            if (tid == 0) { int* ss = s_state[it & 1]; ss[0] = i; ss[1] = j; ss[2] = arr; ss[3] = done ? 1 : 0; }
         }
         __syncthreads();
-        i = s_state[0]; j = s_state[1]; arr = s_state[2]; done = s_state[3] != 0;
-        __syncthreads();
+        { const int* ss = s_state[it & 1]; i = ss[0]; j = ss[1]; arr = ss[2]; done = ss[3] != 0; }
+        it++;
+        // continue in the prefetched tile if the path left the current one inside it
+        const int a = pi - i, c = pj - j;
+        need = !(a >= 0 && c >= 0 && a < BT && c < BT);
+        if (!need) { cur ^= 1; ti = pi; tj = pj; }
     }
 }
 

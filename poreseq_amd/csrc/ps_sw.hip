@@ -212,8 +212,8 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     int* d_out = rt->buf("sw_out").as<int>();
     int* d_res = rt->buf("sw_res").as<int>();
     hipStream_t st = rt->stream2;
-    PS_HIP(hipMemcpyAsync(d_pairs, pairs.data(), np * sizeof(SwPair), hipMemcpyHostToDevice, st));
-    PS_HIP(hipMemcpyAsync(d_chars, pool.data(), pool.size(), hipMemcpyHostToDevice, st));
+    PS_TRY(rt->up(d_pairs, pairs.data(), np * sizeof(SwPair), st));
+    PS_TRY(rt->up(d_chars, pool.data(), pool.size(), st));
     PS_HIP(hipMemsetAsync(d_res, 0, (size_t)np * 8 * sizeof(int), st));
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw0, st));
     for (int d = 0; d < maxdiag; d++)

@@ -347,19 +347,19 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
     short* d_bp = rt->buf("vit_bp").as<short>();
     double* d_fwd = rt->buf("vit_fwd").as<double>();
     double* d_lik = rt->buf("vit_lik").as<double>();
-    PS_HIP(hipMemcpyAsync(d_in, h_obsin, (size_t)T * E * 4 * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+    PS_TRY(rt->up(d_in, h_obsin, (size_t)T * E * 4 * sizeof(double)));
     prof_begin(rt);
     hipLaunchKernelGGL(k_vit_obs, dim3(T), dim3(256), 0, rt->stream, d_in, d_model, E, std::log(2 * M_PI), d_obs, d_eobs);
     hipLaunchKernelGGL(k_vit_steps, dim3(1), dim3(1024), 0, rt->stream, d_obs, d_eobs, T, skip, stay, std::log(skip), std::log(stay),
                        std::log(0.25), d_bp, d_fwd, d_lik, nkeep ? 1 : 0);
     PS_HIP(hipGetLastError());
-    std::vector<double> lik(NS);
-    PS_HIP(hipMemcpyAsync(lik.data(), d_lik, NS * sizeof(double), hipMemcpyDeviceToHost, rt->stream));
+    double* lik = nullptr;
+    PS_TRY(rt->down(&lik, d_lik, (size_t)NS));
     PS_HIP(hipStreamSynchronize(rt->stream));
-    const int start = (int)(std::max_element(lik.begin(), lik.end()) - lik.begin());
+    const int start = (int)(std::max_element(lik, lik + NS) - lik);
     if (nkeep == 0) {
-        std::vector<short> bp((size_t)T * NS);
-        PS_HIP(hipMemcpyAsync(bp.data(), d_bp, bp.size() * sizeof(short), hipMemcpyDeviceToHost, rt->stream));
+        short* bp = nullptr;
+        PS_TRY(rt->down(&bp, d_bp, (size_t)T * NS));
         PS_HIP(hipStreamSynchronize(rt->stream));
         prof_end(rt, "viterbi", (double)T * NS * (8.0 * E + 8 + 2));
         std::vector<int> p(T);
@@ -373,15 +373,15 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
     PS_TRY(rt->buf("vit_att").ensure(nkeep * sizeof(double)));
     PS_TRY(rt->buf("vit_rnd").ensure((size_t)nkeep * T * sizeof(double)));
     PS_TRY(rt->buf("vit_path").ensure((size_t)nkeep * T * sizeof(short)));
-    PS_HIP(hipMemcpyAsync(rt->buf("vit_att").p, att.data(), nkeep * sizeof(double), hipMemcpyHostToDevice, rt->stream));
-    PS_HIP(hipMemcpyAsync(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * T * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+    PS_TRY(rt->up(rt->buf("vit_att").p, att.data(), nkeep * sizeof(double)));
+    PS_TRY(rt->up(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * T * sizeof(double)));
     hipLaunchKernelGGL(k_vit_log, dim3((unsigned)(((size_t)T * NS + 255) / 256)), dim3(256), 0, rt->stream, d_fwd, (size_t)T * NS);
     hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(256), 0, rt->stream, d_fwd, T, start, skip, stay,
                        rt->buf("vit_att").as<double>(), rt->buf("vit_rnd").as<double>(), rt->buf("vit_path").as<short>());
     PS_HIP(hipGetLastError());
     prof_end(rt, "viterbi", (double)T * NS * (8.0 * E + 8 + 2 + 8 + 8.0 * nkeep));
-    std::vector<short> hp((size_t)nkeep * T);
-    PS_HIP(hipMemcpyAsync(hp.data(), rt->buf("vit_path").p, hp.size() * sizeof(short), hipMemcpyDeviceToHost, rt->stream));
+    short* hp = nullptr;
+    PS_TRY(rt->down(&hp, rt->buf("vit_path").p, (size_t)nkeep * T));
     PS_HIP(hipStreamSynchronize(rt->stream));
     for (int k = 0; k < nkeep; k++) {
         std::vector<int> p(T);

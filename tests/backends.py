@@ -59,6 +59,11 @@ _libc = ctypes.CDLL(None)
 def reset_rand():
     """libc rand() is never seeded by the reference (Viterbi.cpp:108): srand(1) == fresh process."""
     _libc.srand(1)
+    try:   # the HIP library draws from a per-thread generator (include/poreseq_hip.h, ps_srand)
+        from poreseq_amd import _capi
+        _capi.load_hip().srand(1)
+    except Exception:
+        pass
 
 
 def make_pa(cls, sequence, events, params):

@@ -1,0 +1,19 @@
+"""Time the realign fill (ScoreEvents = one forward fill of 10 events) per launch (not a test)."""
+import copy, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from poreseq_amd import synth, _capi
+from poreseq_amd.poreseqcpp import PSAlign, swalign
+from poreseq_amd.util import DEFAULT_PARAMS
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+P = dict(DEFAULT_PARAMS, verbose=0)
+if os.environ.get('PS_RW'): P['realign_width'] = int(os.environ['PS_RW'])
+api = _capi.load_hip()
+draft, events, truth = synth.make_region(L, 10, 1002, swalign, P)
+h = api.align_create(draft, copy.deepcopy(events), P)
+api.score_alignments(h, 10)
+api.prof_reset(); api.prof_enable(True)
+t = time.time()
+for rep in range(5):
+    api.score_alignments(h, 10)
+print("RW=%s P>=%s  score_alignments %.2f ms/call; fill prof (ms, launches, bytes) %s" % (
+    P["realign_width"], os.environ.get("PORESEQ_DEBUG_MIN_P", "auto"), 1e3 * (time.time() - t) / 5, api.prof_get("fill")))

@@ -127,6 +127,27 @@ def test_library_exports_every_declared_symbol():
     assert api.backend_name() == "hip-gfx950"
 
 
+def test_hip_library_rand_is_libc_rand_per_thread():
+    """ps_viterbi_mutate's deviates: a per-thread glibc random_r() state == rand() of a fresh process (no GPU needed)."""
+    import ctypes, threading
+    from poreseq_amd import _capi
+    api = _capi.load_hip()
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (1, 1234, 0, 2**32 - 1):
+        libc.srand(seed)
+        want = np.array([libc.rand() for _ in range(20000)]) / (2.0 ** 31)
+        api.srand(seed)
+        assert np.array_equal(api.rand_draw(20000), want)
+    libc.srand(1)
+    fresh = np.array([libc.rand() for _ in range(1000)]) / (2.0 ** 31)
+    got = {}
+    def work(k):
+        got[k] = api.rand_draw(1000)      # never seeded in this thread: the state of an unseeded process
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert all(np.array_equal(got[k], fresh) for k in range(3))
+
+
 def test_product_has_no_path_to_the_oracle():
     pkg = os.path.join(B.ROOT, "poreseq_amd")
     for dp, _, fns in os.walk(pkg):
