@@ -6,12 +6,15 @@
 namespace ps {
 
 struct SwPair {
-    int n1, n2, ntr, ntc;
+    int n1, n2;                  // rows (first sequence), columns (second sequence)
+    int nrb;                     // row blocks of 64
+    int ngw;                     // wave strips (16 per super-strip)
+    int pitch;                   // ints per saved row
+    int pad;
     int64_t s1_off, s2_off;      // into the character pool
-    int64_t steps_off;           // into the step pool: ntr*ntc tiles of TSTEPS*64 bytes
-    int64_t hrow_off;            // 3 * (n2 + 1) ints
-    int64_t hcol_off;            // n1 + 1 ints
-    int64_t tile_off;            // ntr*ntc int4 {score, i, j, 0}
+    int64_t row_off;             // rowsave: nrb x pitch ints, row q = H(64q, 1..n2) at [0..n2)
+    int64_t col_off;             // colsave: (n2/64 + 1) x (n1 + 1) ints, entry c = H(0..n1, 64c)  (c = 0 unused: zeros)
+    int64_t blk_off;             // blkmax: nrb x ngw ints
     int64_t out_off;             // 2 * (n1 + n2 + 2) ints: index pairs in walk order
     int64_t res_off;             // 8 ints: score, bi, bj, npairs, nmatch
 };

@@ -1,169 +1,297 @@
 // ps_sw.hip — full-matrix Smith-Waterman (swfull, cpp/swlib.cpp:211-340) on gfx950.
 //
-// Integer DP, +5 / -4 / -8, bit-exact with the reference including its tie rules
-// (left, then up with strict >, then diagonal with >=; first strict maximum in column-major
-// order starts the traceback; traceback stops at the first score <= 0).
+// Integer DP, +5 / -4 / -8 (linear gaps), bit-exact with the reference including its tie rules (left with >,
+// then up with >, then diagonal with >=, floor 0; the first strict maximum in column-major order starts the
+// traceback; the traceback stops at the first score <= 0).
 //
-// Tiling: 64 rows (one per lane) x TC columns per wave.  Lanes run systolically (lane l is l
-// columns behind lane 0); the value above comes from the neighbour lane by DPP, the tile's top
-// boundary row and left boundary column come from small global arrays written by the tiles
-// above / to the left, which finished on the previous tile anti-diagonal (one launch per tile
-// anti-diagonal, all sequence pairs of a batch in the same launch).
-// Step codes are stored per tile in the order they are produced ([t][lane], 64-byte coalesced
-// stores); the traceback pulls one whole tile into LDS and walks it there.
+// Formulation.  With a linear gap cost the row recurrence  H(i,j) = max(c(i,j), H(i,j-1) - 8),
+// c(i,j) = max(0, H(i-1,j-1) + s, H(i-1,j) - 8)  is a prefix maximum:  H(i,j) + 8j = max_{j'<=j} (c(i,j') + 8j').
+// So a whole row is computed at once — every c from the previous row, then one max-scan across the lanes (DPP) —
+// with no systolic skew: all 64 lanes work on every row.
+//
+// Layout.  One 1024-thread workgroup per sequence pair: lane l of wave w owns K consecutive columns
+// (K = 4 / 8 / 16 chosen from the longest sequence, 16 waves x 64 lanes x K columns = one "super-strip";
+// longer sequences take several super-strips, one launch each).  The waves form a pipeline over rows: in
+// pipeline step s wave w does rows 8(s-w)+1 .. 8(s-w)+8 and hands the H values of its last column to wave
+// w+1 through LDS (one workgroup barrier per 8 rows).  Nothing per cell goes to memory: the fill keeps only
+//   rowsave  H(64q, *)    every 64th row       (top boundaries of 64-row blocks)
+//   colsave  H(*, 64c)    every 64th column    (left boundaries of 64-column blocks)
+//   blkmax   max H per (row block, wave strip)
+// and the traceback kernel recomputes the 64 x 64 tiles its path crosses (the same row routine with one column
+// per lane, this time deriving the 4-bit step codes into LDS) — about 300 of the 25 000 tiles of a 10 kb pair.
+// The starting cell is located by recomputing only the strips whose block maximum equals the global maximum.
 #include "ps_sw.h"
 
 namespace ps {
 
-constexpr int TC = 64;
-constexpr int TSTEPS = ((TC + 63 + 3) / 4) * 4;   // steps per tile, padded to whole 4-step store groups
+constexpr int SWB = 8;    // rows per pipeline step
+constexpr int SWW = 16;   // waves per workgroup
+constexpr bool getenv_nocs = false;
 
-__device__ __forceinline__ int shr1_i(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_max(int v) {   // lanes without a source keep their own value
+    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false));
+}
+// inclusive prefix maximum over the 64 lanes of a wave
+__device__ __forceinline__ int wave_scan_max(int v) {
+    v = dpp_max<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_max<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_max<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_max<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_max<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
+    v = dpp_max<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
+    return v;
 }
 
-__global__ __launch_bounds__(64) void k_sw_tiles(const SwPair* pairs, const char* chars, unsigned char* steps,
-                                                 int* hrow, int* hcol, int4* tiles, int d) {
-    const SwPair p = pairs[blockIdx.y];   // by value: through a reference hipcc re-reads n2 from memory on every step
-    const int rmin = max(0, d - (p.ntc - 1)), rmax = min(p.ntr - 1, d);
-    const int r = rmin + blockIdx.x;
-    if (r > rmax) return;
-    const int c = d - r, l = threadIdx.x;
-    const int i0 = r * 64, j0 = c * TC;
-    const int i = i0 + 1 + l;
-    const bool rowok = i <= p.n1;
+// One row of one wave's strip, in shifted form: the lane's k-th column is carried as G[k] = H + 8k, which turns
+// the in-lane part of the prefix maximum into a plain running max and folds the gap steps into constants
+// (7 integer instructions per cell).  G[] holds row i-1 on entry and row i on return.
+//   c1     character of row i (wave-uniform)          bl     H(i, first column - 1)   (left boundary, uniform)
+//   bprev  H(i-1, first column - 1) (uniform)         lane   lane index, lane0 = lane ? -2^29 : 0
+//   c2[] and c1 hold characters shifted left by 4
+// MODE 0: values only.  MODE 1: also track the column-major first cell equal to `target` in (fc, fr).
+// MODE 2 (K == 1): also return the cell's step code  step | 4*(score > 0) | 8*(characters equal).
+template <int K, int MODE>
+__device__ __forceinline__ unsigned sw_row(int (&G)[K], const int (&c2)[K], const int c1, const int bl, const int bprev,
+                                           const int lane, const int lane0, const int target, const int i, const int jfirst, int& fc, int& fr) {
+    // H(i-1, j-1) of this lane's first column: the previous row's last column of the lane to the left (+ 8(K-1))
+    const int d0 = __builtin_amdgcn_update_dpp(bprev + 8 * (K - 1), G[K - 1], 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    int y[K];
+    int sd0 = 0, up0 = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        // substitution penalty without a compare / select (VALU -> SGPR -> v_cndmask round trips are slow on
+        // gfx950): characters are held shifted left by 4, so c2 ^ c1 is 0 when equal and >= 16 otherwise
+        const int pen = min(c2[k] ^ c1, 9);
+        // diagonal + substitution score, and value above - 8, both shifted by 8k
+        const int sd = (k ? G[k - 1] + 13 : d0 + (5 - 8 * (K - 1))) - pen;
+        const int up = G[k] - 8;
+        if (k == 0) { sd0 = sd; up0 = up; }
+        y[k] = max(max(sd, up), 8 * k);
+    }
+    // running maximum over the lane's columns as a two-level tree (groups of 4): depth 6 instead of K - 1
+    constexpr int NG = (K + 3) / 4;
+    int tg[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+#pragma unroll
+        for (int k = 4 * g + 1; k < min(4 * g + 4, K); k++) y[k] = max(y[k], y[k - 1]);
+        const int last = y[min(4 * g + 3, K - 1)];
+        tg[g] = g ? max(last, tg[g - 1]) : last;
+    }
+    // scan of the lanes' last columns (as H + 8K*lane); the left boundary enters through lane 0
+    int z = tg[NG - 1] + (8 * K * lane - 8 * (K - 1));
+    z = max(z, (bl - 8 * K) + lane0);   // lane0 = 0 in lane 0, -2^29 elsewhere
+    z = wave_scan_max(z);
+    // H(i, first column - 1) of this lane, minus one gap
+    const int hl8 = __builtin_amdgcn_update_dpp(bl - 8 * K, z, 0x138, 0xf, 0xf, false) + (8 * K - 8 * K * lane - 8);
+    unsigned code = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int gn = k >= 4 ? max(max(y[k], tg[k / 4 - 1]), hl8) : max(y[k], hl8);
+        if (MODE == 2 && k == 0) {
+            // reference order (cpp/swlib.cpp:243-263): left with >, up with >, diagonal with >=
+            const int l0 = max(hl8, 0), m = max(l0, up0);
+            const unsigned step = sd0 >= m ? 3u : (up0 > l0 ? 2u : (hl8 > 0 ? 1u : 0u));
+            code = step | (gn > 0 ? 4u : 0u) | (c2[0] == c1 ? 8u : 0u);
+        }
+        if (MODE == 1) {
+            const int col = jfirst + k + 1;
+            if (gn == target + 8 * k && col < fc) { fc = col; fr = i; }
+        }
+        G[k] = gn;
+    }
+    return code;
+}
+
+// ---- fill: grid (pairs), block 1024; one launch per super-strip ------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(1024) void k_sw_fill(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
+                                                  int* blkmax, int ss) {
+    const SwPair p = pairs[blockIdx.x];
+    if (p.n1 <= 0 || p.n2 <= 0 || ss * SWW * 64 * K >= p.n2) return;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int gw = ss * SWW + w;
+    const int wfirst = gw * 64 * K;            // 0-based first column of the wave
+    const bool wave_on = wfirst < p.n2;
+    const int jbase = wfirst + l * K;
     const char* s1 = chars + p.s1_off;
     const char* s2 = chars + p.s2_off;
-    int* hr_prev = hrow + p.hrow_off + (int64_t)((r + 2) % 3) * (p.n2 + 1);
-    int* hr_cur = hrow + p.hrow_off + (int64_t)(r % 3) * (p.n2 + 1);
-    int* hc = hcol + p.hcol_off;
-    __shared__ int s_top[TC + 1];
-    __shared__ int s_bot[TC];
-    __shared__ char s_c2[TC];
-    for (int k = l; k <= TC; k += 64) { const int j = j0 + k; s_top[k] = (r > 0 && j <= p.n2) ? hr_prev[j] : 0; }
-    for (int k = l; k < TC; k += 64) { const int j = j0 + 1 + k; s_c2[k] = j <= p.n2 ? s2[j - 1] : 0; s_bot[k] = 0; }
-    __syncthreads();
-    const char c1 = rowok ? s1[i - 1] : 1;
-    int left = (c > 0 && rowok) ? hc[i] : 0;       // H(i, j0)
-    int h = left;                                  // running H(i, j) of this lane
-    int prevup = shr1_i(left);                     // H(i-1, j0)
-    if (l == 0) prevup = s_top[0];
-    int best = 0, bestt = 0;
-    // columns this lane really has: jj in [0, ncl); it works on them at steps t = l + jj
-    const int ncl = rowok ? min(max(p.n2 - j0, 0), TC) : 0;
-    // step codes: 4 consecutive steps of a lane are packed into one 32-bit store, [t/4][lane][t%4]
-    unsigned* st = (unsigned*)(steps + p.steps_off + (int64_t)(r * p.ntc + c) * TSTEPS * 64);
-    for (int t0 = 0; t0 < TSTEPS; t0 += 4) {
-        // LDS operands of the next four steps, issued together (one lgkmcnt wait per four steps)
-        int tops[4];
-        char ch[4];
+    int c2[K], G[K], bmk[K];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = t0 + u;
-            tops[u] = s_top[min(t + 1, TC)];
-            ch[u] = s_c2[min(max(t - l, 0), TC - 1)];
+    for (int k = 0; k < K; k++) { c2[k] = jbase + k < p.n2 ? (int)(unsigned char)s2[jbase + k] << 4 : 0; G[k] = 8 * k; bmk[k] = 0; }
+    const int lane0 = l ? -(1 << 29) : 0;
+    __shared__ int hand[SWW][2][SWB];
+    // this lane's last column is column jbase + K (1-based); every 64th column is kept as a tile boundary
+    const bool keeps = ((jbase + K) & 63) == 0 && jbase + K <= p.n2;
+    int* csave = colsave + p.col_off + (int64_t)((jbase + K) >> 6) * (p.n1 + 1);
+    const int* cprev = colsave + p.col_off + (int64_t)(wfirst >> 6) * (p.n1 + 1);   // H(*, wfirst): used by wave 0 when ss > 0
+    if (wave_on && keeps) csave[0] = 0;
+    int bprev = 0, dummy_c = 0, dummy_r = 0;
+    const int nchunks = (p.n1 + SWB - 1) / SWB;
+    // row characters (and, for the first wave of a later super-strip, the left boundary) are fetched one chunk
+    // ahead; the workgroup barrier waits for LDS only, so global loads and stores stay in flight across it
+    auto fetch = [&](int c, int& ch, int& bd) {
+        ch = 1; bd = 0;
+        const int i0 = c * SWB;
+        if (wave_on && c >= 0 && c < nchunks && l < SWB && i0 + l < p.n1) {
+            ch = (int)(unsigned char)s1[i0 + l] << 4;
+            if (w == 0 && gw > 0) bd = cprev[i0 + 1 + l];
         }
-        unsigned packed = 0;
+    };
+    int ch_nx, bd_nx;
+    fetch(0 - w, ch_nx, bd_nx);
+    for (int s = 0; s < nchunks + SWW - 1; s++) {
+        const int c = s - w;
+        const int ch1 = ch_nx, bd1 = bd_nx;
+        fetch(c + 1, ch_nx, bd_nx);
+        if (wave_on && c >= 0 && c < nchunks) {
+            const int i0 = c * SWB;
+            int bnd = bd1;
+            if (w > 0 && l < SWB && i0 + l < p.n1) bnd = hand[w - 1][(s - 1) & 1][l];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = t0 + u;
-            const bool act = (unsigned)(t - l) < (unsigned)ncl;
-            int up = shr1_i(h);
-            if (l == 0) up = tops[u];
-            const int diag = prevup;
-            prevup = up;
-            // reference order (cpp/swlib.cpp:243-263): left with >, up with >, diagonal with >=, floor 0
-            const bool eq = c1 == ch[u];
-            const int sd = diag + (eq ? 5 : -4);
-            const int sl = h - 8, su = up - 8;
-            const int l0 = max(sl, 0);
-            const int m = max(l0, su);
-            const int score = max(m, sd);
-            const unsigned step = sd >= m ? 3u : (su > l0 ? 2u : (sl > 0 ? 1u : 0u));
-            const unsigned code = step | (score > 0 ? 4u : 0u) | (eq ? 8u : 0u);
-            packed |= act ? code << (8 * u) : 0u;
-            if (act && score > best) { best = score; bestt = t; }
-            h = act ? score : h;
-            if (l == 63 && t >= 63) s_bot[min(t - 63, TC - 1)] = h;
-        }
-        st[(t0 >> 2) * 64 + l] = packed;
-    }
-    const int bestj = j0 + 1 + (bestt - l);
-    if (rowok) hc[i] = h;
-    // tile maximum: largest score, then smallest column, then smallest row (column-major first hit)
-    int bi = i, bj = best > 0 ? bestj : 0x7fffffff, bs = best;
-    for (int off = 32; off; off >>= 1) {
-        const int os = __shfl_xor(bs, off), oj = __shfl_xor(bj, off), oi = __shfl_xor(bi, off);
-        if (os > bs || (os == bs && (oj < bj || (oj == bj && oi < bi)))) { bs = os; bj = oj; bi = oi; }
-    }
-    if (l == 0) tiles[p.tile_off + r * p.ntc + c] = make_int4(bs, bi, bj, 0);
-    __syncthreads();
-    if (i0 + 64 <= p.n1)
-        for (int k = l; k < TC; k += 64) { const int j = j0 + 1 + k; if (j <= p.n2) hr_cur[j] = s_bot[k]; }
-    if (l == 0 && c == 0) hr_cur[0] = 0;
-}
-
-__global__ __launch_bounds__(64) void k_sw_best(const SwPair* pairs, const int4* tiles, int* res) {
-    const SwPair p = pairs[blockIdx.x];
-    const int l = threadIdx.x, nt = p.ntr * p.ntc;
-    int bs = 0, bi = 0, bj = 0x7fffffff;
-    for (int k = l; k < nt; k += 64) {
-        const int4 v = tiles[p.tile_off + k];
-        if (v.x > bs || (v.x == bs && v.x > 0 && (v.z < bj || (v.z == bj && v.y < bi)))) { bs = v.x; bi = v.y; bj = v.z; }
-    }
-    for (int off = 32; off; off >>= 1) {
-        const int os = __shfl_xor(bs, off), oj = __shfl_xor(bj, off), oi = __shfl_xor(bi, off);
-        if (os > bs || (os == bs && os > 0 && (oj < bj || (oj == bj && oi < bi)))) { bs = os; bj = oj; bi = oi; }
-    }
-    if (l == 0) {
-        int* o = res + p.res_off;
-        o[0] = bs; o[1] = bs > 0 ? bi : 0; o[2] = bs > 0 ? bj : 0;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const unsigned char* steps, int* out, int* res) {
-    const SwPair p = pairs[blockIdx.x];
-    const int l = threadIdx.x;
-    __shared__ unsigned char s_t[TSTEPS * 64];
-    int* o = res + p.res_off;
-    int i = o[1], j = o[2];
-    int np = 0, nm = 0;
-    int* oi = out + p.out_off;
-    int* oj = oi + (p.n1 + p.n2 + 2);
-    bool done = !(i > 0 && j > 0);
-    while (!done) {
-        const int r = (i - 1) / 64, c = (j - 1) / TC;
-        const int i0 = r * 64, j0 = c * TC;
-        const uint4* src = (const uint4*)(steps + p.steps_off + (int64_t)(r * p.ntc + c) * TSTEPS * 64);
-        uint4* dst = (uint4*)s_t;
-        for (int k = l; k < TSTEPS * 4; k += 64) dst[k] = src[k];
-        __syncthreads();
-        if (l == 0) {
-            auto code_at = [&](int ll, int jj) -> unsigned {   // clamped: callers check the real bounds
-                ll = max(ll, 0); jj = max(jj, 0);
-                const int tt = jj + ll;
-                return s_t[((tt >> 2) * 64 + ll) * 4 + (tt & 3)];
-            };
-            int ll = i - i0 - 1, jj = j - j0 - 1;
-            unsigned code = code_at(ll, jj);
-            while (true) {
-                if (!(i > 0 && j > 0)) { done = true; break; }
-                if (ll < 0 || jj < 0) break;  // left this tile
-                // the three possible successors, fetched while this cell is decoded
-                const unsigned cL = code_at(ll, jj - 1), cD = code_at(ll - 1, jj - 1), cU = code_at(ll - 1, jj);
-                if (!(code & 4)) { done = true; break; }   // score <= 0
-                const unsigned stp = code & 3;
-                if (stp == 1) { oi[np] = 0; oj[np] = j; np++; j--; jj--; code = cL; }
-                else if (stp == 2) { oi[np] = i; oj[np] = 0; np++; i--; ll--; code = cU; }
-                else if (stp == 3) { oi[np] = i; oj[np] = j; np++; if (code & 8) nm++; i--; j--; ll--; jj--; code = cD; }
-                else { done = true; break; }
+            for (int r = 0; r < SWB; r++) {
+                if (i0 + r < p.n1) {
+                    const int bl = __builtin_amdgcn_readlane(bnd, r), c1 = __builtin_amdgcn_readlane(ch1, r);
+                    sw_row<K, 0>(G, c2, c1, bl, bprev, l, lane0, 0, 0, 0, dummy_c, dummy_r);
+                    bprev = bl;
+#pragma unroll
+                    for (int k = 0; k < K; k++) bmk[k] = max(bmk[k], G[k]);
+                    const int hlast = G[K - 1] - 8 * (K - 1);
+                    if (l == 63) hand[w][s & 1][r] = hlast;
+                    if (keeps) csave[i0 + r + 1] = hlast;
+                }
+            }
+            const int iend = min(i0 + SWB, p.n1);
+            if ((iend & 63) == 0 || iend == p.n1) {   // row block q complete
+                const int q = (iend - 1) >> 6;
+                int bm = 0;
+#pragma unroll
+                for (int k = 0; k < K; k++) { bm = max(bm, bmk[k] - 8 * k); bmk[k] = 0; }
+                for (int o = 32; o; o >>= 1) bm = max(bm, __shfl_xor(bm, o));
+                if (l == 0) blkmax[p.blk_off + (int64_t)q * p.ngw + gw] = bm;
+                if (iend < p.n1) {                    // row 64(q+1) is the top boundary of block q+1
+                    int* rs = rowsave + p.row_off + (int64_t)(q + 1) * p.pitch + jbase;
+#pragma unroll
+                    for (int k = 0; k < K; k++) if (jbase + k < p.n2) rs[k] = G[k] - 8 * k;
+                }
             }
         }
-        i = __shfl(i, 0); j = __shfl(j, 0); np = __shfl(np, 0); nm = __shfl(nm, 0);
-        done = __shfl((int)done, 0) != 0;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (l == 0) { o[3] = np; o[4] = nm; }
+}
+
+// recompute rows 64q+1 .. 64q+nrows of the strip of 64K columns that starts at 0-based column c0 (a multiple of 64); one wave
+template <int K, int MODE>
+__device__ __forceinline__ void sw_tile(const SwPair& p, const char* s1, const char* s2, const int* rowsave, const int* colsave,
+                                        const int q, const int c0, const int nrows, const int l, const int target, int& fc, int& fr,
+                                        unsigned char (*codes)[64]) {
+    const int jbase = c0 + l * K;
+    int c2[K], G[K];
+    const int* rs = rowsave + p.row_off + (int64_t)q * p.pitch + jbase;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const bool ok = jbase + k < p.n2;
+        c2[k] = ok ? (int)(unsigned char)s2[jbase + k] << 4 : 0;
+        G[k] = ((ok && q > 0) ? rs[k] : 0) + 8 * k;
+    }
+    const int* cprev = colsave + p.col_off + (int64_t)(c0 >> 6) * (p.n1 + 1);   // H(*, c0)
+    int bprev = c0 > 0 ? cprev[64 * q] : 0;
+    int bnd = 0, ch1 = 1;
+    if (l < nrows) { ch1 = (int)(unsigned char)s1[64 * q + l] << 4; if (c0 > 0) bnd = cprev[64 * q + 1 + l]; }
+    const int lane0 = l ? -(1 << 29) : 0;
+    for (int r = 0; r < nrows; r++) {
+        const int bl = __builtin_amdgcn_readlane(bnd, r), c1 = __builtin_amdgcn_readlane(ch1, r);
+        const unsigned cd = sw_row<K, MODE>(G, c2, c1, bl, bprev, l, lane0, target, 64 * q + r + 1, jbase, fc, fr);
+        if (MODE == 2) codes[r][l] = (unsigned char)cd;   // MODE 2 runs with K == 1
+        bprev = bl;
+    }
+}
+
+// ---- locate the starting cell, then trace back; grid (pairs), block 64 ------------------------------------------
+template <int K>
+__global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const char* chars, const int* rowsave, const int* colsave,
+                                                 const int* blkmax, int* out, int* res) {
+    __shared__ unsigned char codes[64][64];
+    const SwPair p = pairs[blockIdx.x];
+    const int l = threadIdx.x;
+    int* o = res + p.res_off;
+    const char* s1 = chars + p.s1_off;
+    const char* s2 = chars + p.s2_off;
+    const int* bmx = blkmax + p.blk_off;
+    int best = 0;
+    if (p.n1 > 0 && p.n2 > 0)
+        for (int k = l; k < p.nrb * p.ngw; k += 64) best = max(best, bmx[k]);
+    for (int s = 32; s; s >>= 1) best = max(best, __shfl_xor(best, s));
+    if (best <= 0) {
+        if (l == 0) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; }
+        return;
+    }
+    // first cell with the maximum in column-major order: smallest column, then smallest row
+    int bi = 0, bj = 0;
+    for (int gw = 0; gw < p.ngw && !bj; gw++) {
+        int fc = 0x7fffffff, fr = 0x7fffffff;
+        for (int q0 = 0; q0 < p.nrb; q0 += 64) {
+            const int q = q0 + l;
+            unsigned long long hit = __ballot(q < p.nrb && bmx[(int64_t)q * p.ngw + gw] == best);
+            while (hit) {
+                const int qq = q0 + (int)__builtin_ctzll(hit);
+                hit &= hit - 1;
+                sw_tile<K, 1>(p, s1, s2, rowsave, colsave, qq, gw * 64 * K, min(64, p.n1 - 64 * qq), l, best, fc, fr, codes);
+            }
+        }
+        for (int s = 32; s; s >>= 1) {
+            const int oc = __shfl_xor(fc, s), orow = __shfl_xor(fr, s);
+            if (oc < fc || (oc == fc && orow < fr)) { fc = oc; fr = orow; }
+        }
+        if (fc != 0x7fffffff) { bj = fc; bi = fr; }
+    }
+    int* oi = out + p.out_off;
+    int* oj = oi + (p.n1 + p.n2 + 2);
+    int i = bi, j = bj, np = 0, nm = 0;
+    bool done = false;
+    while (!done && i > 0 && j > 0) {
+        const int q = (i - 1) >> 6, cb = (j - 1) >> 6;   // 64 x 64 tile holding (i, j), one column per lane
+        const int r0 = 64 * q + 1, cfirst = 64 * cb + 1;
+        int dc = 0, dr = 0;
+        __syncthreads();
+        sw_tile<1, 2>(p, s1, s2, rowsave, colsave, q, 64 * cb, i - 64 * q, l, 0, dc, dr, codes);
+        __syncthreads();
+        // lane m looks m cells ahead on the diagonal: a run of diagonal steps is emitted at once
+        while (true) {
+            if (!(i > 0 && j > 0)) { done = true; break; }
+            if (i < r0 || j < cfirst) break;   // left the tile
+            const int ii = i - l, jj = j - l;
+            unsigned code = 0;
+            if (ii >= r0 && jj >= cfirst) code = codes[ii - r0][jj - cfirst];
+            const unsigned long long dm = __ballot((code & 7u) == 7u);   // diagonal step from a cell with score > 0
+            const int run = __builtin_amdgcn_readfirstlane(dm == ~0ull ? 64 : (int)__builtin_ctzll(~dm));
+            if (l < run) { oi[np + l] = ii; oj[np + l] = jj; }
+            nm += (int)__popcll(__ballot((code & 8u) && l < run));
+            np += run; i -= run; j -= run;
+            if (run == 64) continue;
+            if (!(i > 0 && j > 0)) { done = true; break; }
+            if (i < r0 || j < cfirst) break;
+            const unsigned cr = __builtin_amdgcn_readlane(code, run);
+            if (!(cr & 4u)) { done = true; break; }   // score <= 0
+            const unsigned stp = cr & 3u;
+            if (stp == 1u) { if (l == 0) { oi[np] = 0; oj[np] = j; } np++; j--; }
+            else if (stp == 2u) { if (l == 0) { oi[np] = i; oj[np] = 0; } np++; i--; }
+            else { done = true; break; }
+        }
+    }
+    if (l == 0) { o[0] = best; o[1] = bi; o[2] = bj; o[3] = np; o[4] = nm; }
+}
+
+template <int K>
+static int sw_run(Runtime* rt, hipStream_t st, int np, int nss, const SwPair* d_pairs, const char* d_chars, int* d_row, int* d_col,
+                  int* d_blk, int* d_out, int* d_res) {
+    for (int ss = 0; ss < nss; ss++)
+        hipLaunchKernelGGL(k_sw_fill<K>, dim3(np), dim3(1024), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, ss);
+    PS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_sw_trace<K>, dim3(np), dim3(64), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -175,53 +303,54 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     std::vector<SwPair>& pairs = job->pairs;
     std::string& pool = job->pool;
     pairs.assign(np, SwPair());
-    int64_t steps_tot = 0, hrow_tot = 0, hcol_tot = 0, tile_tot = 0, out_tot = 0;
-    int maxdiag = 0, maxtiles = 0;
+    int maxn2 = 1;
+    for (int k = 0; k < np; k++) maxn2 = std::max(maxn2, (int)in[k].second->size());
+    const int K = maxn2 <= 4096 ? 4 : maxn2 <= 8192 ? 8 : 16;
+    const int sswidth = SWW * 64 * K;
+    const int nss = (maxn2 + sswidth - 1) / sswidth;
+    int64_t row_tot = 0, col_tot = 0, blk_tot = 0, out_tot = 0;
     for (int k = 0; k < np; k++) {
         SwPair& p = pairs[k];
         p.n1 = (int)in[k].first->size(); p.n2 = (int)in[k].second->size();
-        p.ntr = std::max(1, (p.n1 + 63) / 64); p.ntc = std::max(1, (p.n2 + TC - 1) / TC);
+        p.nrb = std::max(1, (p.n1 + 63) / 64);
+        p.ngw = SWW * std::max(1, (p.n2 + sswidth - 1) / sswidth);
+        p.pitch = ((p.n2 + 3) / 4) * 4 + 4;
         p.s1_off = (int64_t)pool.size(); pool += *in[k].first;
         p.s2_off = (int64_t)pool.size(); pool += *in[k].second;
-        p.steps_off = steps_tot; steps_tot += (int64_t)p.ntr * p.ntc * TSTEPS * 64;
-        p.hrow_off = hrow_tot; hrow_tot += 3 * ((int64_t)p.n2 + 1);
-        p.hcol_off = hcol_tot; hcol_tot += (int64_t)p.n1 + 1;
-        p.tile_off = tile_tot; tile_tot += (int64_t)p.ntr * p.ntc;
+        p.row_off = row_tot; row_tot += (int64_t)p.nrb * p.pitch;
+        p.col_off = col_tot; col_tot += ((int64_t)p.n2 / 64 + 1) * (p.n1 + 1);
+        p.blk_off = blk_tot; blk_tot += (int64_t)p.nrb * p.ngw;
         p.out_off = out_tot; out_tot += 2 * ((int64_t)p.n1 + p.n2 + 2);
         p.res_off = (int64_t)k * 8;
-        maxdiag = std::max(maxdiag, p.ntr + p.ntc - 1);
-        maxtiles = std::max(maxtiles, std::min(p.ntr, p.ntc));
         job->cells += (double)p.n1 * p.n2;
     }
     pool.push_back(0);
     job->out_tot = out_tot;
     PS_TRY(rt->buf("sw_pairs").ensure(np * sizeof(SwPair)));
     PS_TRY(rt->buf("sw_chars").ensure(pool.size()));
-    PS_TRY(rt->buf("sw_steps").ensure(steps_tot));
-    PS_TRY(rt->buf("sw_hrow").ensure(hrow_tot * sizeof(int)));
-    PS_TRY(rt->buf("sw_hcol").ensure(hcol_tot * sizeof(int)));
-    PS_TRY(rt->buf("sw_tiles").ensure(tile_tot * sizeof(int4)));
+    PS_TRY(rt->buf("sw_row").ensure(row_tot * sizeof(int)));
+    PS_TRY(rt->buf("sw_col").ensure(col_tot * sizeof(int)));
+    PS_TRY(rt->buf("sw_blk").ensure(blk_tot * sizeof(int)));
     PS_TRY(rt->buf("sw_out").ensure(out_tot * sizeof(int)));
     PS_TRY(rt->buf("sw_res").ensure((size_t)np * 8 * sizeof(int)));
     SwPair* d_pairs = rt->buf("sw_pairs").as<SwPair>();
     char* d_chars = rt->buf("sw_chars").as<char>();
-    unsigned char* d_steps = rt->buf("sw_steps").as<unsigned char>();
-    int* d_hrow = rt->buf("sw_hrow").as<int>();
-    int* d_hcol = rt->buf("sw_hcol").as<int>();
-    int4* d_tiles = rt->buf("sw_tiles").as<int4>();
+    int* d_row = rt->buf("sw_row").as<int>();
+    int* d_col = rt->buf("sw_col").as<int>();
+    int* d_blk = rt->buf("sw_blk").as<int>();
     int* d_out = rt->buf("sw_out").as<int>();
     int* d_res = rt->buf("sw_res").as<int>();
     hipStream_t st = rt->stream2;
     PS_TRY(rt->up(d_pairs, pairs.data(), np * sizeof(SwPair), st));
     PS_TRY(rt->up(d_chars, pool.data(), pool.size(), st));
     PS_HIP(hipMemsetAsync(d_res, 0, (size_t)np * 8 * sizeof(int), st));
+    PS_HIP(hipMemsetAsync(d_blk, 0, blk_tot * sizeof(int), st));   // waves beyond a pair's last column never write theirs
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw0, st));
-    for (int d = 0; d < maxdiag; d++)
-        hipLaunchKernelGGL(k_sw_tiles, dim3(maxtiles, np), dim3(64), 0, st, d_pairs, d_chars, d_steps, d_hrow, d_hcol, d_tiles, d);
-    PS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_sw_best, dim3(np), dim3(64), 0, st, d_pairs, d_tiles, d_res);
-    hipLaunchKernelGGL(k_sw_trace, dim3(np), dim3(64), 0, st, d_pairs, d_steps, d_out, d_res);
-    PS_HIP(hipGetLastError());
+    switch (K) {
+        case 4: PS_TRY(sw_run<4>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res)); break;
+        case 8: PS_TRY(sw_run<8>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res)); break;
+        default: PS_TRY(sw_run<16>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res)); break;
+    }
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw1, st));
     PS_TRY(rt->hbuf("sw_res").ensure((size_t)np * 8 * sizeof(int)));
     PS_TRY(rt->hbuf("sw_out").ensure((size_t)out_tot * sizeof(int)));
