@@ -28,8 +28,26 @@ import time
 
 # concurrent regions need more than HIP's default 4 hardware queues; must be set before HIP initialises
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-# cap the DP-matrix bytes of one seed batch per host thread (R threads share one GPU's HBM)
-os.environ.setdefault("PORESEQ_MAX_BATCH_GB", "8")
+
+
+def _pre_hip_env(argv):
+    """Per-thread resources depend on how many regions share the GPU; both knobs are read when HIP initialises."""
+    R = 16
+    for k, a in enumerate(argv):
+        if a == "--regions-per-gpu" and k + 1 < len(argv):
+            R = int(argv[k + 1])
+        elif a.startswith("--regions-per-gpu="):
+            R = int(a.split("=", 1)[1])
+    # cap the DP-matrix bytes of one seed batch per host thread (R threads share one GPU's HBM)
+    os.environ.setdefault("PORESEQ_MAX_BATCH_GB", "8" if R <= 8 else "4")
+    # more than ~20 HIP streams oversubscribe the hardware queues (measured cliff between 10 and 11 regions with two
+    # streams each): beyond 10 regions every region uses one stream (its Smith-Waterman batch then overlaps with
+    # other regions' work instead of its own realign)
+    if R > 10:
+        os.environ.setdefault("PORESEQ_ONE_STREAM", "1")
+
+
+_pre_hip_env(sys.argv)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -44,7 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--events", type=int, default=10)
-    ap.add_argument("--regions-per-gpu", type=int, default=8, help="independent regions refined concurrently on one GPU")
+    ap.add_argument("--regions-per-gpu", type=int, default=16, help="independent regions refined concurrently on one GPU")
     ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()

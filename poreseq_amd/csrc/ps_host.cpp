@@ -146,7 +146,7 @@ int runtime(Runtime** out) {
             // was measured and made no difference, so it is not used.
             if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
                 hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess ||
-                hipStreamCreateWithFlags(&R.stream2, hipStreamNonBlocking) != hipSuccess ||
+                (getenv("PORESEQ_ONE_STREAM") ? ((R.stream2 = R.stream), hipSuccess) : hipStreamCreateWithFlags(&R.stream2, hipStreamNonBlocking)) != hipSuccess ||
                 hipEventCreate(&R.ev0) != hipSuccess || hipEventCreate(&R.ev1) != hipSuccess ||
                 hipEventCreate(&R.sw0) != hipSuccess || hipEventCreate(&R.sw1) != hipSuccess) {
                 state = -1; why = "HIP device initialisation failed";

@@ -183,15 +183,19 @@ __global__ __launch_bounds__(256) void k_lo(BatchD b, int ndir) {
 
 // ------------------------------------------------------------------------------------------------
 // emission pass: for every (s, slot) write EM = emission (or 0) and FLG = band flags
-// grid (nblk, njobs*ndir), block 256; the event's 48 KB model is staged in LDS
+// grid (nblk, njobs*ndir), block 1024 (16 waves share the event's 48 KB model in LDS: two blocks per CU give full
+// occupancy).  The work unit is one wave-wide run of 64 slots of one anti-diagonal; every wave walks a contiguous
+// range of units, so the anti-diagonal index and everything derived from it (LO[s], its residue mod P) is
+// wave-uniform and no per-cell division is needed.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
+constexpr int EMIS_T = 1024;
+__global__ __launch_bounds__(EMIS_T) void k_emis(BatchD b, int ndir) {
     __shared__ double s_model[6 * NS];
     const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
     if (b.out[job].inert) return;
     const double* gm = b.model + (size_t)J.ev * 6 * NS;
-    for (int k = threadIdx.x; k < 6 * NS; k += 256) s_model[k] = gm[k];
+    for (int k = threadIdx.x; k < 6 * NS; k += EMIS_T) s_model[k] = gm[k];
     __syncthreads();
     const int P = J.P, n0 = J.n0, C = J.C, W = J.W;
     const int* __restrict__ lb = b.lb + J.lb_off;
@@ -202,14 +206,29 @@ __global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
     const double* __restrict__ lsdv = b.logstdv + J.lev_off;
     double* __restrict__ em = b.em + J.mat_off[dir];
     unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
-    const int64_t ncell = J.S * P;
-    for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < ncell; cell += (int64_t)gridDim.x * 256) {
-        const int s = (int)(cell / P), slot = (int)(cell - (int64_t)s * P);
+    const int lane = threadIdx.x & 63;
+    const int nP = P >> 6;                                   // P is a multiple of 64
+    const int64_t nunits = J.S * nP;
+    const int64_t nwaves = (int64_t)gridDim.x * (EMIS_T / 64);
+    const int64_t per = (nunits + nwaves - 1) / nwaves;
+    const int64_t u0 = min(nunits, ((int64_t)blockIdx.x * (EMIS_T / 64) + (threadIdx.x >> 6)) * per);
+    const int64_t u1 = min(nunits, u0 + per);
+    int s = __builtin_amdgcn_readfirstlane((int)(u0 / nP));
+    int c = __builtin_amdgcn_readfirstlane((int)(u0 - (int64_t)s * nP));
+    int lo = -1, lom = 0;
+    bool fresh = true;
+    for (int64_t u = u0; u < u1; u++) {
+        if (fresh) {   // a new anti-diagonal: its first in-band row and that row's slot
+            lo = __builtin_amdgcn_readfirstlane(LO[s]);
+            lom = lo >= 0 ? lo % P : 0;
+            fresh = false;
+        }
+        const int slot = c * 64 + lane;
         unsigned f = 0;
         double e = 0.0;
-        const int lo = LO[s];
         if (lo >= 0) {
-            const int d = (slot - lo % P + P) % P;
+            int d = slot - lom;
+            if (d < 0) d += P;
             const int i = lo + d, j = s - i;
             if (i <= n0 && j >= 1 && j <= C) {
                 int i0, i1;
@@ -235,8 +254,10 @@ __global__ __launch_bounds__(256) void k_emis(BatchD b, int ndir) {
                 }
             }
         }
+        const int64_t cell = (int64_t)s * P + slot;
         em[cell] = e;
         flg[cell] = (unsigned short)f;
+        if (++c == nP) { c = 0; s++; fresh = true; }
     }
 }
 
@@ -405,14 +426,22 @@ __global__ __launch_bounds__(256) void k_steps(BatchD b, int ndir) {
     unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
     unsigned long long* gcmax = (unsigned long long*)(b.cmax + J.col_off[dir]);
     const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
-    for (int idx = threadIdx.x; idx < nst * P; idx += 256) {
-        const int k = idx / P, slot = idx - k * P;
+    // work unit = one wave-wide run of 64 slots of one anti-diagonal (k, c): k and LO are wave-uniform
+    const int nP = P >> 6, lane = threadIdx.x & 63;
+    int k = 0, c = threadIdx.x >> 6;
+    while (c >= nP) { c -= nP; k++; }
+    for (; k < nst; ) {
         const int64_t s = s0 + k;
+        const int slot = c * 64 + lane;
         const int64_t cell = s * P + slot;
-        const unsigned f = flg[cell];
+        const int lo = __builtin_amdgcn_readfirstlane(LO[s]);
+        const unsigned f = lo >= 0 ? flg[cell] : 0u;
+        c += 4;
+        while (c >= nP) { c -= nP; k++; }
         if (!(f & F_ACT)) continue;
-        const int lo = LO[s];
-        const int i = lo + (slot - lo % P + P) % P;
+        int d = slot - lo % P;
+        if (d < 0) d += P;
+        const int i = lo + d;
         const int j = (int)s - i;
         const double2 v = rec[cell];
         if (v.x > 0.0) {
@@ -862,9 +891,10 @@ int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS) {
 
 int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols) {
     if (!b.njobs) return PS_OK;
-    int nblk = (int)std::min<int64_t>((maxS * P + 256 * 16 - 1) / (256 * 16), std::max(16, 4096 / (b.njobs * ndir)));
+    // ~2048 workgroups of 16 waves over the chip, at least ~64 wave-units per wave
+    int nblk = (int)std::min<int64_t>((maxS * (P / 64) + 16 * 64 - 1) / (16 * 64), std::max(4, 2048 / (b.njobs * ndir)));
     nblk = std::max(nblk, 1);
-    hipLaunchKernelGGL(k_emis, dim3(nblk, b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
+    hipLaunchKernelGGL(k_emis, dim3(nblk, b.njobs * ndir), dim3(EMIS_T), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     prof_begin(rt);
     hipLaunchKernelGGL(k_recur, dim3(b.njobs * ndir), dim3(P), 2 * P * sizeof(double4), rt->stream, b, ndir);

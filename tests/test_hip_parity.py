@@ -160,6 +160,26 @@ def test_sw_parity_and_properties():
     assert swalign("", "ACGT")[1] == []
 
 
+def test_sw_all_strip_widths_and_super_strips_match_oracle():
+    """Every column-per-lane variant of the fill (4 / 8 / 16), a second super-strip (> 16384 columns), repeats
+    (many equal maxima: the column-major first one must start the traceback) and unrelated sequences."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for n1, n2 in [(4100, 4096), (4096, 4097), (6000, 8192), (3000, 8193), (9000, 9500), (2500, 16400), (1300, 17000)]:
+        s1 = synth.random_sequence(rng, n1)
+        s2 = synth.corrupt(rng, s1, 0.04, 0.04, 0.04)
+        s2 = (s2 + synth.random_sequence(rng, n2))[:n2]
+        cases.append((s1, s2))
+    unit = synth.random_sequence(rng, 37)
+    cases.append((unit * 60, unit * 130))                       # tandem repeat: ties everywhere
+    cases.append((synth.random_sequence(rng, 5000), synth.random_sequence(rng, 5200)))   # unrelated
+    cases.append(("ACGT" * 300, "TGCA" * 1100))
+    for s1, s2 in cases:
+        a, b = swalign(s1, s2), B.oracle_swalign(s1, s2)
+        assert a[1] == b[1], (len(s1), len(s2))
+        assert (a[0] == b[0]) or (np.isnan(a[0]) and np.isnan(b[0]))
+
+
 def test_edge_cases_match_oracle():
     draft, events, truth = synth.make_region(150, 4, 51, B.oracle_swalign, P0, draft_error=0.0)
     ev = copy.deepcopy(events)
