@@ -37,7 +37,7 @@ typedef enum ps_status {
     PS_ERR_BAD_ARG = -1,     /* NULL pointer, negative size, negative mutation start ... */
     PS_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init */
     PS_ERR_HIP = -3,         /* a HIP call failed */
-    PS_ERR_UNSUPPORTED = -4, /* e.g. realign_width > 511 (band wider than one workgroup) */
+    PS_ERR_UNSUPPORTED = -4, /* e.g. realign_width > 510 (band wider than one workgroup) */
     PS_ERR_NOMEM = -5
 } ps_status;
 

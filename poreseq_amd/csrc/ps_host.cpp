@@ -210,8 +210,8 @@ int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int n
     ndir = ndir_;
     const int W = a->par.realign_width;
     if (W < 0) return fail(PS_ERR_BAD_ARG, "realign_width < 0");
-    Pmax = std::max(64, ((2 * W + 1 + 63) / 64) * 64);
-    if (Pmax > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 511: band wider than one workgroup");
+    Pmax = std::max(64, ((2 * W + 3 + 63) / 64) * 64);   // widest possible footprint 2W + 1, plus the two idle slots k_recur relies on
+    if (Pmax > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 510: band wider than one workgroup");
     P = 0;
     jobs.clear();
     maxS = 0; maxC = 0; maxn = 0; maxlbn = 0;
@@ -243,6 +243,8 @@ int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int n
         jobs.push_back(j);
     }
     ncols = col_tot;
+    has_invalid = false;
+    for (int v : h_states) if (v < 0) { has_invalid = true; break; }
     PS_TRY(rt->buf("jobs").ensure(jobs.size() * sizeof(JobD)));
     PS_TRY(rt->buf("states").ensure(std::max<size_t>(h_states.size(), 1) * sizeof(int)));
     PS_TRY(rt->buf("lb").ensure(std::max<int64_t>(lb_tot, 1) * sizeof(int)));
@@ -270,7 +272,7 @@ int Batch::place(Runtime* rt, int P_) {
     int64_t mat_tot = 0;
     for (JobD& j : jobs) {
         j.P = P;
-        // + 8 spare anti-diagonals: k_recur's padded last prefetch group stores (and k_steps never reads) there
+        // + 8 spare anti-diagonals (REC_PAD): zero flags from k_emis, touched by k_recur's padded last prefetch groups
         for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot; mat_tot += (j.S + 8) * P; }
     }
     cells = mat_tot;
@@ -403,9 +405,9 @@ int realign(Runtime* rt, Align* a, Batch& b, int lb_extra_ready) {
     PS_HIP(hipStreamSynchronize(rt->stream));
     int w = 1;
     for (int k = 0; k < b.d.njobs; k++) w = std::max(w, o[k].maxw);
-    PS_TRY(b.place(rt, w));
+    PS_TRY(b.place(rt, w + 2));   // two slots more than the widest footprint: every lane idles between two rows (k_recur)
     if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes(a);
-    PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P, b.ncols));
+    PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P, b.ncols, b.has_invalid));
     PS_TRY(launch_backtrace(rt, b.d, b.maxn));
     PS_TRY(launch_updaterefs(rt, b.d));
     return PS_OK;

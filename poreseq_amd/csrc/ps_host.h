@@ -32,6 +32,7 @@ struct Batch {
     BatchD d;
     int ndir = 1, P = 0, Pmax = 64, maxC = 0, maxn = 0, maxlbn = 0;
     int64_t maxS = 0, cells = 0, ncols = 0;
+    bool has_invalid = false;   // some job's sequence has an invalid 5-mer (state -1)
     int build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int ndir, int lb_extra, bool matrices = true);
     int place(Runtime* rt, int P);
     double fill_alg_bytes(const Align* a) const;

@@ -162,7 +162,7 @@ struct BatchD {
 int launch_updaterefs(Runtime* rt, const BatchD& b);
 int launch_lb(Runtime* rt, const BatchD& b, int which /*0: lb_off, 1: lbn_off*/, int maxlbn);
 int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS);
-int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols);
+int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols, bool has_invalid);
 int launch_backtrace(Runtime* rt, const BatchD& b, int maxn);
 
 struct ScoreArgs {

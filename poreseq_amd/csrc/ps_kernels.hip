@@ -32,8 +32,9 @@
 
 namespace ps {
 
-enum : unsigned { F_ACT = 1, F_VL = 2, F_VD = 4, F_TOP = 8, F_INV = 16, F_BLANK = 32,
-                  F_RL = 64 /* left value is a real stored cell */, F_RD = 128 /* diagonal value is a real stored cell */ };
+enum : unsigned { F_ACT = 1, F_VL = 2, F_VD = 4, F_TOP = 8, F_BLANK = 32,
+                  F_RD = 128 /* the diagonal neighbour's value counts (see recur_step) */ };
+constexpr unsigned FLG_DEAD = 0xC000u;   // final step word of a cell in an invalid-5-mer column: both scores <= 0, no move
 enum : unsigned { M_SKIP = 0, M_MATCH = 1, M_INSERT = 2, M_IGNORE = 3, M_STAY = 4, M_EXTEND = 5, M_IMPL = 255 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -188,6 +189,8 @@ __global__ __launch_bounds__(256) void k_lo(BatchD b, int ndir) {
 // range of units, so the anti-diagonal index and everything derived from it (LO[s], its residue mod P) is
 // wave-uniform and no per-cell division is needed.
 // ------------------------------------------------------------------------------------------------
+constexpr int PF = 3;            // anti-diagonals per prefetch group of k_recur (two groups ping-pong in registers)
+constexpr int REC_PAD = 2 * PF;  // spare anti-diagonals behind every matrix: the padded last groups of k_recur touch them
 constexpr int EMIS_T = 1024;
 __global__ __launch_bounds__(EMIS_T) void k_emis(BatchD b, int ndir) {
     __shared__ double s_model[6 * NS];
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(EMIS_T) void k_emis(BatchD b, int ndir) {
     unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
     const int lane = threadIdx.x & 63;
     const int nP = P >> 6;                                   // P is a multiple of 64
-    const int64_t nunits = J.S * nP;
+    const int64_t nunits = (J.S + REC_PAD) * nP;             // the spare anti-diagonals get zero flags (k_recur reads them)
     const int64_t nwaves = (int64_t)gridDim.x * (EMIS_T / 64);
     const int64_t per = (nunits + nwaves - 1) / nwaves;
     const int64_t u0 = min(nunits, ((int64_t)blockIdx.x * (EMIS_T / 64) + (threadIdx.x >> 6)) * per);
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(EMIS_T) void k_emis(BatchD b, int ndir) {
     bool fresh = true;
     for (int64_t u = u0; u < u1; u++) {
         if (fresh) {   // a new anti-diagonal: its first in-band row and that row's slot
-            lo = __builtin_amdgcn_readfirstlane(LO[s]);
+            lo = s < J.S ? __builtin_amdgcn_readfirstlane(LO[s]) : -1;
             lom = lo >= 0 ? lo % P : 0;
             fresh = false;
         }
@@ -234,17 +237,21 @@ __global__ __launch_bounds__(EMIS_T) void k_emis(BatchD b, int ndir) {
                 int i0, i1;
                 band_of(lb, dir, j, C, n0, W, i0, i1);
                 if (i >= i0 && i <= i1) {
-                    f = F_ACT;
-                    int p0, p1;
-                    if (j == 1) { p0 = 0; p1 = n0; f |= F_BLANK; }
-                    else band_of(lb, dir, j - 1, C, n0, W, p0, p1);
-                    if (i >= p0 && i <= p1) f |= F_VL | (j == 1 ? 0u : F_RL);
-                    if (i > p0 && i <= p1) f |= F_VD | (j == 1 ? 0u : F_RD);
-                    if (i == i0) f |= F_TOP;
                     const int state = st[dir == 0 ? j - 1 : C - j];
                     if (state < 0) {
-                        f |= F_INV;
+                        // invalid 5-mer: the whole column is zero (cpp/Alignment.cpp:162-163).  Its step word is
+                        // final here; k_recur treats the cell like one outside the band (the same implicit zero for
+                        // its right-hand neighbours) and k_invfix stores the zero record afterwards.
+                        f = FLG_DEAD;
                     } else {
+                        f = F_ACT;
+                        int p0, p1;
+                        if (j == 1) { p0 = 0; p1 = n0; f |= F_BLANK; }
+                        else band_of(lb, dir, j - 1, C, n0, W, p0, p1);
+                        if (i >= p0 && i <= p1) f |= F_VL;
+                        // (a diagonal neighbour in an invalid-5-mer column is a zero as well: leave F_RD clear)
+                        if (i > p0 && i <= p1) f |= F_VD | ((j == 1 || st[dir == 0 ? j - 2 : C - j + 1] < 0) ? 0u : F_RD);
+                        if (i == i0) f |= F_TOP;
                         ModelRow m = {s_model[state], s_model[NS + state], s_model[2 * NS + state],
                                       s_model[3 * NS + state], s_model[4 * NS + state], s_model[5 * NS + state]};
                         // forward reads level i-1 but log_stdv[n0-i] (sic, cpp/Alignment.cpp:171-172); backward reads level n0-i
@@ -276,46 +283,59 @@ __device__ __forceinline__ double wave_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
-constexpr int PF = 4;        // anti-diagonals per prefetch group (two groups ping-pong in registers)
-constexpr int REC_PAD = 2 * PF;  // spare anti-diagonals behind every matrix: the padded last group stores there
 
 template <int DIR>
 struct RecurState {
-    double cm = 0.0, cs = 0.0, co = 0.0;   // this lane's latest main / stay / emission
-    double upm = 0.0, upo = 0.0;           // what the upper neighbour published one step ago
-    int par = 0;
+    double cm, cs;             // this lane's latest main / stay; -infinity while it has no cell
+    double pe = 0.0;           // backward pass: the emission this step's upper neighbour had one step earlier
+    unsigned hist = 0;         // wave-uniform: bit k set = the wave had a cell k anti-diagonals ago
+    int wa[3], ra[3];          // LDS byte offsets of this lane's slot / its upper neighbour's slot in the three buffers
 };
 
-// one anti-diagonal.  Every input is gated by a band flag (F_RL / F_RD / F_TOP), so a lane's registers
-// and its exchange slot may hold anything while it has no cell; the cell's result is stored
-// unconditionally ((s, slot) pairs outside the band are never read by anyone).  Neighbour values go
-// through LDS for all lanes alike: one ds_write + one ds_read per step instead of DPP shifts plus
-// separate lane-0 / lane-63 hand-over code.
-template <int DIR>
+// one anti-diagonal; PH = (anti-diagonal index) mod 3 selects the roles of the three exchange buffers.
+//
+// A lane without an in-band cell holds and publishes -infinity for main and stay.  Read as the upper neighbour
+// (row i-1 one step ago) that is what the stay / extend / insert moves of a band's top row need; read as the left
+// neighbour (the lane's own previous value) fmax(.., 0) turns it into the reference's "implicit zero" for
+// neighbours outside the previous band (cpp/Alignment.cpp:201-225) and leaves real scores, which are >= 0,
+// untouched.  This needs no flags because P exceeds the widest band footprint by two slots and the band edges
+// move at most one row per anti-diagonal: a lane always idles for at least one step between two different rows.
+// Cells of invalid-5-mer columns are all zero; k_emis finishes them and marks them idle.
+// Two inputs keep a flag.  F_TOP: the stay matrix of a top row starts from -1e300 instead of 0.  F_RD: the
+// diagonal neighbour is taken only when this cell's own row lies inside the previous column's band — the
+// reference tests row i, not row i-1, against that band, so on the row just below the previous band's last row it
+// reads zero although cell (i-1, j-1) exists.
+// Neighbour values go through LDS for all lanes alike, in three rotating buffers: a cell reads what row i-1
+// published one step ago (upper neighbour) and two steps ago (diagonal neighbour) while this step's results go
+// to the third.  The backward recurrence adds the emission of the cell a move comes FROM (cpp/Alignment.cpp:
+// 284-330); those are plain reads of the emission matrix one slot up, one and two anti-diagonals back (`o` is that
+// stream in the backward pass, the cell's own emission in the forward pass), not part of the exchange.  A wave whose cells have all left the band runs three more all-idle steps, which put -infinity
+// into its slots of all three buffers, and then only takes part in the barrier until a cell comes back.
+template <int DIR, int PH>
 __device__ __forceinline__ void recur_step(RecurState<DIR>& r, const double o, const unsigned f, double2* __restrict__ dst,
-                                           double4* __restrict__ xch, const int slot, const int up_slot, const int P,
-                                           const double lsk, const double lst, const double lex, const double lin) {
+                                           char* __restrict__ xch, const double lsk, const double lst, const double lex,
+                                           const double lin) {
     const double NINF = -__builtin_inf();
-    if (__builtin_amdgcn_ballot_w64(f & F_ACT) != 0ull) {
-        // {main, stay[, emission]} of row i-1 after the previous step (the forward pass moves 16 bytes, the backward 32)
-        double4 u;
-        if (DIR) u = xch[r.par * P + up_slot];
-        else { const double2 u2 = ((const double2*)xch)[r.par * P + up_slot]; u = make_double4(u2.x, u2.y, 0.0, 0.0); }
-        const double L = (f & F_RL) ? r.cm : 0.0;
-        const double D = (f & F_RD) ? r.upm : 0.0;
-        const double po = (f & F_RD) ? r.upo : 0.0;
-        r.upm = u.x;
-        if (DIR) r.upo = u.z;
-        const bool top = f & F_TOP;
-        const double ume = top ? NINF : u.x, use = top ? NINF : u.y;
-        const double eo = DIR == 0 ? o : u.z;
-        const double cSTAY = ume + eo + lst;
-        const double cEXT = use + eo + lex;
-        const double cINS = ume + lin;
+    // scalar bookkeeping: number of lanes with a cell (s_bcnt1) -> one history bit per anti-diagonal
+    const unsigned nact = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(f & F_ACT));
+    r.hist = ((r.hist << 1) & 14u) | min(nact, 1u);
+    if (r.hist) {
+        constexpr int W0 = PH, R1 = (PH + 2) % 3, R2 = (PH + 1) % 3;   // written now / one step ago / two steps ago
+        // {main, stay} of row i-1 one step ago, main two steps ago
+        const double2 u = *(const double2*)(xch + r.ra[R1]);
+        const double dx = *(const double*)(xch + r.ra[R2]);
+        const bool rd = f & F_RD;
+        double L;   // max(cm, 0) in one instruction (fmax() would first canonicalise its operand)
+        asm("v_max_f64 %0, %1, 0" : "=v"(L) : "v"(r.cm));
+        const double D = rd ? dx : 0.0, po = rd ? r.pe : 0.0;
+        const double eo = o;
+        const double cSTAY = u.x + eo + lst;
+        const double cEXT = u.y + eo + lex;
+        const double cINS = u.x + lin;
         const double cSKIP = L + lsk;
         const double cMATCH = DIR == 0 ? D + o : D + po;
         const double cIGN = D + lin;
-        double ns = top ? -BIG : 0.0;
+        double ns = (f & F_TOP) ? -BIG : 0.0;
         ns = fmax(ns, cSTAY);
         ns = fmax(ns, cEXT);
         double nm = fmax(0.0, cSKIP);
@@ -323,46 +343,52 @@ __device__ __forceinline__ void recur_step(RecurState<DIR>& r, const double o, c
         nm = fmax(nm, cINS);
         nm = fmax(nm, cIGN);
         nm = fmax(nm, ns);
-        const bool inv = f & F_INV;       // invalid 5-mer: the whole column is zero (cpp/Alignment.cpp:162-163)
-        r.cm = inv ? 0.0 : nm;
-        r.cs = inv ? 0.0 : ns;
-        if (DIR) r.co = inv ? 0.0 : o;
+        const bool act = f & F_ACT;
+        r.cm = act ? nm : NINF;
+        r.cs = act ? ns : NINF;
         *dst = make_double2(r.cm, r.cs);
-        if (DIR) xch[(r.par ^ 1) * P + slot] = make_double4(r.cm, r.cs, r.co, 0.0);
-        else ((double2*)xch)[(r.par ^ 1) * P + slot] = make_double2(r.cm, r.cs);
+        *(double2*)(xch + r.wa[W0]) = make_double2(r.cm, r.cs);
     }
+    if (DIR) r.pe = o;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    r.par ^= 1;
 }
 
 template <int DIR>
-__device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, double4* __restrict__ xch) {
+__device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, char* __restrict__ xch) {
     const int P = J.P, slot = threadIdx.x;
     const int up_slot = slot == 0 ? P - 1 : slot - 1;
     const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
-    const double* __restrict__ em = b.em + J.mat_off[DIR] + slot;
+    // forward: the cell's own emission; backward: the emission of the cell one slot up on the previous anti-diagonal
+    const double* __restrict__ em = b.em + J.mat_off[DIR] + (DIR ? up_slot - P : slot);
     const unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR] + slot;
     double2* __restrict__ rec = b.rec + J.mat_off[DIR] + slot;
     const int64_t S = J.S, SL = S - 1;
+    constexpr int RB = 16;   // bytes per exchanged record {main, stay}
+    const double NINF = -__builtin_inf();
     RecurState<DIR> r;
-    xch[slot] = make_double4(0.0, 0.0, 0.0, 0.0);
-    xch[P + slot] = make_double4(0.0, 0.0, 0.0, 0.0);
+    r.cm = NINF; r.cs = NINF;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        r.wa[k] = (k * P + slot) * RB;
+        r.ra[k] = (k * P + up_slot) * RB;
+        *(double2*)(xch + r.wa[k]) = make_double2(NINF, NINF);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     double eA[PF], eB[PF];
     unsigned fA[PF], fB[PF];
+    // no tail handling: k_emis wrote zero flags on the REC_PAD spare anti-diagonals behind the matrix, which the
+    // padded last groups read (and, as idle lanes, store to).  PF is a multiple of 3, so the buffer roles are
+    // compile-time constants of the unrolled step index.
 #define PS_LOAD(E, F, s0)                                                   \
     _Pragma("unroll") for (int u = 0; u < PF; u++) {                        \
-        const int64_t sc = min((int64_t)(s0) + u, SL) * P;                  \
+        const int64_t sc = min((int64_t)(s0) + u, SL + REC_PAD) * P;        \
         E[u] = em[sc];                                                      \
         F[u] = flg[sc];                                                     \
     }
-#define PS_RUN(E, F, s0)                                                    \
-    _Pragma("unroll") for (int u = 0; u < PF; u++) {                        \
-        const int64_t sv = (int64_t)(s0) + u;                               \
-        const unsigned f = sv < S ? F[u] : 0u;                              \
-        recur_step<DIR>(r, E[u], f, rec + sv * P, xch, slot, up_slot, P, lsk, lst, lex, lin); \
-    }
+#define PS_STEP(E, F, s0, u) recur_step<DIR, (u) % 3>(r, E[u], F[u], rec + ((int64_t)(s0) + (u)) * P, xch, lsk, lst, lex, lin);
+#define PS_RUN(E, F, s0) PS_STEP(E, F, s0, 0) PS_STEP(E, F, s0, 1) PS_STEP(E, F, s0, 2)
+    static_assert(PF == 3, "PS_RUN is written out for three steps per group");
     PS_LOAD(eA, fA, 2)
     for (int64_t s0 = 2; s0 < S; s0 += 2 * PF) {   // every wave runs the same padded trip count
         PS_LOAD(eB, fB, s0 + PF)
@@ -371,11 +397,26 @@ __device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, doubl
         PS_RUN(eB, fB, s0 + PF)
     }
 #undef PS_LOAD
+#undef PS_STEP
 #undef PS_RUN
 }
 
+// zero records of the invalid-5-mer cells (k_recur leaves -infinity in idle slots); launched only for batches whose
+// sequences contain an invalid 5-mer.  grid (nblk, njobs*ndir), block 256
+__global__ __launch_bounds__(256) void k_invfix(BatchD b, int ndir) {
+    const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
+    const JobD& J = b.jobs[job];
+    if (b.out[job].inert) return;
+    const unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
+    double2* __restrict__ rec = b.rec + J.mat_off[dir];
+    const int64_t ncell = J.S * J.P;
+    for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < ncell; cell += (int64_t)gridDim.x * 256)
+        if (flg[cell] == FLG_DEAD) rec[cell] = make_double2(0.0, 0.0);
+}
+
 __global__ __launch_bounds__(1024) void k_recur(BatchD b, int ndir) {
-    extern __shared__ double4 xch[];   // [2][P]
+    extern __shared__ double2 xch2[];   // three exchange buffers of P {main, stay} records
+    char* xch = (char*)xch2;
     const int jd = blockIdx.x, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
     if (b.out[job].inert) return;
@@ -450,7 +491,7 @@ __global__ __launch_bounds__(256) void k_steps(BatchD b, int ndir) {
         }
         if (dir == 0) {
             unsigned sm = 0, ss = 0;
-            if (!(f & F_INV)) {
+            {
                 const int sm1 = slot == 0 ? P - 1 : slot - 1;
                 const double o = em[cell];
                 double L = 0.0, D = 0.0, um = 0.0, us = 0.0;
@@ -889,7 +930,7 @@ int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS) {
     return PS_OK;
 }
 
-int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols) {
+int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols, bool has_invalid) {
     if (!b.njobs) return PS_OK;
     // ~2048 workgroups of 16 waves over the chip, at least ~64 wave-units per wave
     int nblk = (int)std::min<int64_t>((maxS * (P / 64) + 16 * 64 - 1) / (16 * 64), std::max(4, 2048 / (b.njobs * ndir)));
@@ -897,9 +938,13 @@ int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int
     hipLaunchKernelGGL(k_emis, dim3(nblk, b.njobs * ndir), dim3(EMIS_T), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     prof_begin(rt);
-    hipLaunchKernelGGL(k_recur, dim3(b.njobs * ndir), dim3(P), 2 * P * sizeof(double4), rt->stream, b, ndir);
+    hipLaunchKernelGGL(k_recur, dim3(b.njobs * ndir), dim3(P), 3 * P * sizeof(double2), rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     prof_end(rt, "fill", 0.0);
+    if (has_invalid) {
+        hipLaunchKernelGGL(k_invfix, dim3(std::max(1, 1024 / (b.njobs * ndir)), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
+        PS_LAUNCH_CHECK();
+    }
     PS_HIP(hipMemsetAsync(b.cmax, 0, ncols * sizeof(double), rt->stream));
     hipLaunchKernelGGL(k_steps, dim3((unsigned)((maxS + SB - 1) / SB), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();

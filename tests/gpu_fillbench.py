@@ -11,6 +11,14 @@ api = _capi.load_hip()
 draft, events, truth = synth.make_region(L, 10, 1002, swalign, P)
 h = api.align_create(draft, copy.deepcopy(events), P)
 api.score_alignments(h, 10)
+if os.environ.get("PS_MODE") == "score":     # realign with both directions (ScoreMutations on a short list)
+    rng = __import__("numpy").random.default_rng(1)
+    muts = synth.random_point_mutations(rng, draft, 50)
+    hm = api.muts_create(muts)
+    for rep in range(6):
+        api.muts_destroy(api.score_mutations(h, hm))
+    print("score mode done")
+    sys.exit(0)
 api.prof_reset(); api.prof_enable(True)
 t = time.time()
 for rep in range(5):
