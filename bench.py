@@ -5,8 +5,8 @@ One "step" = the full `poreseq consensus` schedule (Mutate('self') then up to 4 
 Refine()}, poreseq/Mutate.py:70-85) over one BATCH of R independent synthetic regions, each 10 kb with 10
 event streams (BASELINE.json configs[1]), through the drop-in PSAlign API and the C ABI.  Regions are the
 reference's own unit of parallelism (one process per region file, README.md:48-54); a single region keeps
-only a few dozen of the 256 CUs busy, so one GPU refines R regions concurrently (one host thread + HIP
-stream pair per region).  With N GPUs every rank refines its own batch per step (weak scaling) and the value
+only a few dozen of the 256 CUs busy, so one GPU refines R regions concurrently (default 16; one host thread
+with its own HIP stream(s), device pools and random stream per region).  With N GPUs every rank refines its own batch per step (weak scaling) and the value
 is the whole-job rate:  N * R * region_kb * K / max-over-ranks time.  The latency of one region processed
 alone is reported as well.
 
