@@ -74,7 +74,7 @@ def variant_region(pa, muts, region_start=0, params=None, out=None):
     return mutscores
 
 
-def train(make_pa, params, refseq, iters=1, reps=10, save=None, paramlists=None):
+def train(make_pa, params, refseq, iters=1, reps=10, save=None, paramlists=None, in_flight=1):
     """Transition-parameter search of `poreseq train` (cmdline.py:246-267): each iteration runs the consensus
     schedule (reps = 10) once per perturbed parameter set and keeps the most accurate one.
 
@@ -82,16 +82,24 @@ def train(make_pa, params, refseq, iters=1, reps=10, save=None, paramlists=None)
     transition probabilities taken from `params` (what LoadAlignedEvents + setparams do in the reference);
     the 16 replicas are independent region work-items.  `paramlists` (optional) replaces VaryParams, e.g.
     for reproducible tests.  Returns (best params, best accuracy per iteration).
+
+    in_flight > 1 runs that many replicas concurrently on the GPU (one host thread each).  The reference runs them
+    one after another in one process, so the stochastic Viterbi seeds of replica k continue the rand() stream
+    of replica k-1; concurrent replicas each continue their own thread's stream instead (as 16 separate
+    `poreseq consensus` processes would), which can change which replica wins by chance — keep 1 for parity.
     """
     from .util import VaryParams, SaveParams
     best_accs = []
     for it in range(iters):
         paramlist = paramlists[it] if paramlists is not None else VaryParams(params)
-        accs = []
-        for p in paramlist:
-            pa = make_pa(p)
-            _seq, acc = consensus_region(pa, p, reps=reps, refseq=refseq)
-            accs.append(acc)
+        def one(p):
+            return consensus_region(make_pa(p), p, reps=reps, refseq=refseq)[1]
+        if in_flight > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=int(in_flight)) as pool:
+                accs = list(pool.map(one, paramlist))
+        else:
+            accs = [one(p) for p in paramlist]
         params = paramlist[int(np.argmax(accs))]
         if save:
             SaveParams(save, params)

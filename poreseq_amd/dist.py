@@ -95,12 +95,36 @@ def gather_regions(local_results, n_regions, max_events):
     return out
 
 
-def run_regions(regions, process, max_events=64):
-    """Shard `regions` over the ranks, run process(region) -> (sequence, scores) locally, gather."""
+def _fresh_region_rand():
+    """Every region starts from the random stream of a fresh process — the reference runs one `poreseq consensus`
+    process per region file and never seeds rand() (Viterbi.cpp:108) — whichever thread refines it."""
+    from . import _capi
+    _capi.load_hip().srand(1)
+
+
+def run_regions(regions, process, max_events=64, in_flight=1, fresh_rand=_fresh_region_rand):
+    """Shard `regions` over the ranks, run process(region) -> (sequence, scores) locally, gather.
+
+    in_flight > 1 refines that many of this rank's regions concurrently on its GPU, one host thread each (the
+    library gives every thread its own streams and device pools; a single region keeps only a few percent of an
+    MI355X busy).  Results do not depend on in_flight: `fresh_rand` (default: ps_srand(1) on the HIP library) is
+    called in the worker before each region.
+    """
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    local = []
-    for idx, reg in shard(regions, rank, world):
+    mine = shard(regions, rank, world)
+
+    def one(item):
+        idx, reg = item
+        if fresh_rand is not None:
+            fresh_rand()
         seq, sc = process(reg)
-        local.append((idx, seq, sc))
+        return (idx, seq, sc)
+
+    if in_flight > 1 and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(in_flight)) as pool:
+            local = list(pool.map(one, mine))
+    else:
+        local = [one(it) for it in mine]
     return gather_regions(local, len(regions), max_events)

@@ -98,3 +98,28 @@ def test_concurrent_regions_from_threads_match_oracle():
     [t.join() for t in th]
     for k in range(3):
         assert np.array_equal(got[k], want[k])
+
+
+def test_run_regions_in_flight_is_deterministic_and_matches_fresh_process_oracle():
+    """The region driver with several regions in flight per GPU: every region is the full stochastic consensus
+    schedule (ViterbiMutate draws random numbers), results equal the one-at-a-time run and the oracle run of a
+    fresh process (srand(1) before each region) — whichever worker thread picks a region up."""
+    from poreseq_amd import dist as psdist
+    specs = [(350 + 20 * k, 5, 900 + k) for k in range(5)]
+    made = {s: synth.make_region(s[0], s[1], s[2], B.oracle_swalign, P0) for s in specs}
+
+    def process(cls):
+        def f(spec):
+            d, e, _t = made[spec]
+            pa = B.make_pa(cls, d, copy.deepcopy(e), P0)
+            seq, _ = consensus_region(pa, P0)
+            return seq, np.array(pa.ScoreEvents())
+        return f
+
+    one = psdist.run_regions(specs, process(PSAlign), max_events=8, in_flight=1)
+    many = psdist.run_regions(specs, process(PSAlign), max_events=8, in_flight=3)
+    assert [r[0] for r in one] == [r[0] for r in many]
+    assert all(np.array_equal(a[1], b[1]) for a, b in zip(one, many))
+    ref = psdist.run_regions(specs[:2], process(B.OraclePSAlign), max_events=8, in_flight=1, fresh_rand=B.reset_rand)
+    assert [r[0] for r in ref] == [r[0] for r in one[:2]]
+    assert all(np.array_equal(a[1], b[1]) for a, b in zip(ref, one[:2]))
