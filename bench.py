@@ -162,10 +162,22 @@ def main():
         dom = max(prof, key=lambda k: prof[k][0])
         ms, launches, nbytes = prof[dom]
         achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": {"fill": "k_recur", "score": "k_score", "sw": "k_sw_tiles",
-                                                      "viterbi": "k_vit_steps"}[dom],
+        kname = {"fill": "k_recur", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}[dom]
+        # HBM-side bytes per launch from the PMC counters cannot be collected from inside this process; they are
+        # measured offline with rocprofv3 on the same workload shape (tools/pmc_total.sh) and committed under profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_g_traffic_per_launch.json")) as fh:
+                tk = json.load(fh)["kernels"].get(kname)
+            if tk and args.length == 10000 and args.events == 10:
+                traffic = tk["fetch_bytes_per_launch"] + tk["write_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
+        out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+                           "traffic": traffic, "traffic_source": "profiles/r01_g_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE + "
+                                                                  "WRITE_SIZE per launch, offline, same workload shape)" if traffic else None,
+                           "launches": launches, "avg_launch_ms": ms / max(launches, 1),
                            "alg_bytes_per_launch": nbytes / max(launches, 1),
                            "all_kernel_classes_ms": {k: v[0] for k, v in prof.items()}}
 

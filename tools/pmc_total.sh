@@ -14,5 +14,8 @@ for r in csv.DictReader(open(sys.argv[1])):
 print(sys.argv[2], "total %.1f GB (counter unit KB x 1024)" % (sum(tot.values()) * 1024 / 1e9))
 for k, v in tot.most_common(10):
     print("   %-30s %8.2f GB  in %5d dispatches" % (k[:30], v * 1024 / 1e9, n[k]))
+import json, os
+out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "prof", "traffic_%s.json" % sys.argv[2])
+json.dump({k: {"bytes_per_launch": tot[k] * 1024 / n[k], "launches": n[k]} for k in tot}, open(out, "w"), indent=1)
 PY
 done
