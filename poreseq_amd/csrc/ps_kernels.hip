@@ -299,7 +299,8 @@ struct RecurState {
 // neighbour (the lane's own previous value) fmax(.., 0) turns it into the reference's "implicit zero" for
 // neighbours outside the previous band (cpp/Alignment.cpp:201-225) and leaves real scores, which are >= 0,
 // untouched.  This needs no flags because P exceeds the widest band footprint by two slots and the band edges
-// move at most one row per anti-diagonal: a lane always idles for at least one step between two different rows.
+// move at most one row per anti-diagonal (the band centres are bisection results, hence non-decreasing in the
+// column for any ref_index): a lane always idles for at least one step between two different rows.
 // Cells of invalid-5-mer columns are all zero; k_emis finishes them and marks them idle.
 // Two inputs keep a flag.  F_TOP: the stay matrix of a top row starts from -1e300 instead of 0.  F_RD: the
 // diagonal neighbour is taken only when this cell's own row lies inside the previous column's band — the
