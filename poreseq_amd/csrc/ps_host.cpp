@@ -6,6 +6,7 @@
 #include "ps_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -118,6 +119,13 @@ struct RtHolder {
 thread_local RtHolder t_rt;
 }  // namespace
 
+int second_stream(Runtime* rt, hipStream_t* out) {
+    if (getenv("PORESEQ_ONE_STREAM")) { *out = rt->stream; return PS_OK; }
+    if (!rt->stream2) PS_HIP(hipStreamCreateWithFlags(&rt->stream2, hipStreamNonBlocking));
+    *out = rt->stream2;
+    return PS_OK;
+}
+
 int runtime(Runtime** out) {
     if (!t_rt.s) {
         std::lock_guard<std::mutex> lk(g_rt_mu);
@@ -141,12 +149,12 @@ int runtime(Runtime** out) {
             else if (const char* s2 = getenv("LOCAL_RANK")) dev = atoi(s2) % n;
             if (dev < 0 || dev >= n) dev = 0;
             hipDeviceProp_t prop;
-            // Two non-blocking streams: alignment fills on one, Smith-Waterman batches on the other (they
-            // overlap inside FindMutations).  Partitioning the CUs between them (hipExtStreamCreateWithCUMask)
-            // was measured and made no difference, so it is not used.
+            // One non-blocking stream for the alignment pipeline; a second one for Smith-Waterman batches (they
+            // overlap with the base realign inside FindMutations) is created on first use (second_stream()).
+            // Partitioning the CUs between them (hipExtStreamCreateWithCUMask) was measured and made no
+            // difference, so it is not used.
             if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
                 hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess ||
-                (getenv("PORESEQ_ONE_STREAM") ? ((R.stream2 = R.stream), hipSuccess) : hipStreamCreateWithFlags(&R.stream2, hipStreamNonBlocking)) != hipSuccess ||
                 hipEventCreate(&R.ev0) != hipSuccess || hipEventCreate(&R.ev1) != hipSuccess ||
                 hipEventCreate(&R.sw0) != hipSuccess || hipEventCreate(&R.sw1) != hipSuccess) {
                 state = -1; why = "HIP device initialisation failed";
@@ -160,7 +168,7 @@ int runtime(Runtime** out) {
     if (state < 0) return fail(PS_ERR_NO_DEVICE, why);
     if (R.stage.dirty) {   // a new API call: nothing staged by the previous one may still be in flight
         PS_HIP(hipStreamSynchronize(R.stream));
-        PS_HIP(hipStreamSynchronize(R.stream2));
+        if (R.stream2) PS_HIP(hipStreamSynchronize(R.stream2));
         PS_TRY(R.stage.reset());
     }
     *out = &R;

@@ -95,6 +95,12 @@ struct Runtime {
     template <class T> int down(T** hptr, const void* src, size_t count) { return down((void**)hptr, src, count * sizeof(T)); }
 };
 int runtime(Runtime** out);  // PS_ERR_NO_DEVICE when no usable GPU; never falls back
+// The stream Smith-Waterman batches should use: the runtime's second stream (created on first use), so that the
+// batch overlaps with the base realign of FindMutations — unless PORESEQ_ONE_STREAM is set, which a driver does when
+// it keeps more than ~10 regions in flight on one GPU: with that many host threads the hardware queues are
+// oversubscribed by second streams (measured: 10 concurrent regions with two streams each run at full speed, 11 fall
+// off a cliff, 16-20 regions with one stream each are fine), and the overlap comes from the other regions anyway.
+int second_stream(Runtime* rt, hipStream_t* out);
 
 // ---- mutation list (vector<MutInfo>/vector<MutScore>, cpp/AlignUtil.h:69-91) ----------------
 struct Mut {

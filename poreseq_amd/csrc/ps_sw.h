@@ -30,10 +30,11 @@ struct SwJob {
     int64_t out_tot = 0;
     double cells = 0;
     int np = 0;
+    hipStream_t stream = nullptr;   // where the batch was enqueued
 };
 
 typedef std::vector<std::pair<const std::string*, const std::string*>> SwInput;
-int sw_launch(Runtime* rt, const SwInput& in, SwJob* job);   // asynchronous, on rt->stream2
+int sw_launch(Runtime* rt, const SwInput& in, SwJob* job);   // asynchronous, on the runtime's second stream (or its main one under load)
 int sw_finish(Runtime* rt, SwJob* job, std::vector<SwResult>* out);
 int sw_batch(Runtime* rt, const SwInput& in, std::vector<SwResult>* out);
 

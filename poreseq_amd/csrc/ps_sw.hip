@@ -340,7 +340,9 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     int* d_blk = rt->buf("sw_blk").as<int>();
     int* d_out = rt->buf("sw_out").as<int>();
     int* d_res = rt->buf("sw_res").as<int>();
-    hipStream_t st = rt->stream2;
+    hipStream_t st = nullptr;
+    PS_TRY(second_stream(rt, &st));
+    job->stream = st;
     PS_TRY(rt->up(d_pairs, pairs.data(), np * sizeof(SwPair), st));
     PS_TRY(rt->up(d_chars, pool.data(), pool.size(), st));
     PS_HIP(hipMemsetAsync(d_res, 0, (size_t)np * 8 * sizeof(int), st));
@@ -365,7 +367,7 @@ int sw_finish(Runtime* rt, SwJob* job, std::vector<SwResult>* out) {
     const int np = job->np;
     out->assign(np, SwResult());
     if (!np) return PS_OK;
-    PS_HIP(hipStreamSynchronize(rt->stream2));
+    PS_HIP(hipStreamSynchronize(job->stream));
     if (rt->prof_on) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, rt->sw0, rt->sw1) == hipSuccess) {

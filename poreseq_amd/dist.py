@@ -121,6 +121,8 @@ def run_regions(regions, process, max_events=64, in_flight=1, fresh_rand=_fresh_
         seq, sc = process(reg)
         return (idx, seq, sc)
 
+    if in_flight > 10:
+        os.environ.setdefault("PORESEQ_ONE_STREAM", "1")   # see second_stream() in csrc/ps_host.cpp
     if in_flight > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=int(in_flight)) as pool:
