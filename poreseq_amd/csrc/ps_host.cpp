@@ -34,6 +34,8 @@ void Tick::lap(const char* label) {
 // ------------------------------------------------------------------------------------------ runtime
 int DBuf::ensure(size_t bytes) {
     if (bytes <= cap && p) return PS_OK;
+    static const bool trace = getenv("PORESEQ_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[ps] pool grow %zu -> %zu bytes\n", cap, bytes);
     if (p) { PS_HIP(hipFree(p)); p = nullptr; cap = 0; }
     size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
     if (hipMalloc(&p, want) != hipSuccess) {
