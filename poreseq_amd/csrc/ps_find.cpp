@@ -381,11 +381,9 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
     tk.lap("gather levels");
     if (T == 0) return PS_OK;
     // uniform deviates in the reference's call order: for each kept path, one per back-step (cpp/Viterbi.cpp:108)
-    std::vector<double> rnd((size_t)nkeep * T);
-    for (size_t k = 0; k < rnd.size(); k++) rnd[k] = rand_next() / (double(RAND_MAX) + 1);
-    tk.lap("rand");
+    auto draw = [](double* rnd, size_t n) { for (size_t k = 0; k < n; k++) rnd[k] = rand_next() / (double(RAND_MAX) + 1); };
     std::vector<std::vector<int>> paths;
-    PS_TRY(viterbi_device(rt, E, T, obsin.data(), a->d_model, nkeep, skip, stay, mmin, mmax, rnd.data(), &paths));
+    PS_TRY(viterbi_device(rt, E, T, obsin.data(), a->d_model, nkeep, skip, stay, mmin, mmax, draw, &paths));
     tk.lap("device");
     for (auto& p : paths) out->push_back(path_to_bases(p));
     tk.lap("paths to bases");

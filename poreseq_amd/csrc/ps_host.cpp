@@ -514,6 +514,13 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
     }
     extra = std::max(extra, 0) + 2;
     if (ncolmax > 64 && WS > 511) return fail(PS_ERR_UNSUPPORTED, "edit longer than 58 bases with scoring_width > 511");
+    // Alignment::update for every event: enqueued now, so that the fills run while the host prepares the edit tables
+    tk.lap("edit sizes");
+    Batch b;
+    PS_TRY(a->base_batch(rt, &b, 2, extra));
+    PS_TRY(realign(rt, a, b, extra));
+    a->host_refs_valid = false;
+    tk.lap("realign enqueue");
     std::vector<int> h_states((size_t)M * ncolmax, -1);
     {
         auto work = [&](int lo, int hi) {
@@ -545,8 +552,6 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
         cls[nc <= 8 ? 0 : nc <= 16 ? 1 : nc <= 32 ? 2 : 3].push_back(i);
     }
     tk.lap("edit geometry");
-    Batch b;
-    PS_TRY(a->base_batch(rt, &b, 2, extra));
     // upload edit tables
     const int nr0 = (int)r0s.size();
     DBuf& mb = rt->buf("mutint");
@@ -568,12 +573,9 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
     const size_t dbl = (size_t)a->E * std::max(nr0, 1) + (size_t)a->E * std::max(M, 1) + std::max(M, 1);
     PS_TRY(db.ensure(dbl * sizeof(double)));
     sa.old = db.as<double>(); sa.delta = sa.old + (size_t)a->E * std::max(nr0, 1); sa.score = sa.delta + (size_t)a->E * std::max(M, 1);
-    // Alignment::update for every event, then every edit against every event
     tk.lap("upload");
-    PS_TRY(realign(rt, a, b, extra));
     if (tk.on) { PS_HIP(hipStreamSynchronize(rt->stream)); }
-    tk.lap("realign fwd+back");
-    a->host_refs_valid = false;
+    tk.lap("realign fwd+back (rest)");
     PS_TRY(launch_lb(rt, b.d, 1, b.maxlbn));
     if (M) {
         if (rt->prof_on) {

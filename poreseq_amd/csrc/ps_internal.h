@@ -200,7 +200,8 @@ int sw_device(Runtime* rt, const std::string& s1, const std::string& s2, int* sc
 struct VitStepH { int refind; };
 int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin /*[T][E][4]: lvl, sd, logsd, present*/,
                    const double* d_model, int nkeep, double skip, double stay, double mmin, double mmax,
-                   const double* h_rand /*[nkeep][T]*/, std::vector<std::vector<int>>* paths);
+                   void (*draw)(double* /*[nkeep][T]*/, size_t) /* draws the deviates; called while the recursion runs */,
+                   std::vector<std::vector<int>>* paths);
 
 void prof_begin(Runtime* rt);
 void prof_end(Runtime* rt, const char* name, double alg_bytes);

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_vit_trace(const double* __restrict__ lf
 }
 
 int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const double* d_model, int nkeep,
-                   double skip, double stay, double mmin, double mmax, const double* h_rand,
+                   double skip, double stay, double mmin, double mmax, void (*draw)(double*, size_t),
                    std::vector<std::vector<int>>* paths) {
     paths->clear();
     if (T <= 0) return PS_OK;
@@ -355,6 +355,13 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
     PS_HIP(hipGetLastError());
     double* lik = nullptr;
     PS_TRY(rt->down(&lik, d_lik, (size_t)NS));
+    // the uniform deviates of the stochastic back-traces are drawn on the host while the recursion runs
+    double* h_rand = nullptr;
+    if (nkeep > 0) {
+        h_rand = (double*)rt->stage.alloc((size_t)nkeep * T * sizeof(double));
+        if (!h_rand) return fail(PS_ERR_NOMEM, "hipHostMalloc (staging arena)");
+        draw(h_rand, (size_t)nkeep * T);
+    }
     PS_HIP(hipStreamSynchronize(rt->stream));
     const int start = (int)(std::max_element(lik, lik + NS) - lik);
     if (nkeep == 0) {
@@ -374,7 +381,7 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
     PS_TRY(rt->buf("vit_rnd").ensure((size_t)nkeep * T * sizeof(double)));
     PS_TRY(rt->buf("vit_path").ensure((size_t)nkeep * T * sizeof(short)));
     PS_TRY(rt->up(rt->buf("vit_att").p, att.data(), nkeep * sizeof(double)));
-    PS_TRY(rt->up(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * T * sizeof(double)));
+    PS_HIP(hipMemcpyAsync(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * T * sizeof(double), hipMemcpyHostToDevice, rt->stream));
     hipLaunchKernelGGL(k_vit_log, dim3((unsigned)(((size_t)T * NS + 255) / 256)), dim3(256), 0, rt->stream, d_fwd, (size_t)T * NS);
     hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(256), 0, rt->stream, d_fwd, T, start, skip, stay,
                        rt->buf("vit_att").as<double>(), rt->buf("vit_rnd").as<double>(), rt->buf("vit_path").as<short>());
