@@ -9,9 +9,10 @@
 // So a whole row is computed at once — every c from the previous row, then one max-scan across the lanes (DPP) —
 // with no systolic skew: all 64 lanes work on every row.
 //
-// Layout.  One 1024-thread workgroup per sequence pair: lane l of wave w owns K consecutive columns
-// (K = 4 / 8 / 16 chosen from the longest sequence, 16 waves x 64 lanes x K columns = one "super-strip";
-// longer sequences take several super-strips, one launch each).  The waves form a pipeline over rows: in
+// Layout.  Lane l of wave w owns K consecutive columns (K = 4 or 8 chosen from the longest sequence); 8 waves x
+// 64 lanes x K columns = one "super-strip" = one 512-thread workgroup, and a pair takes as many super-strips as
+// its columns need, all in the same launch and pipelined over rows like the waves inside one (a 10 kb pair runs
+// on three CUs).  The waves form a pipeline over rows: in
 // pipeline step s wave w does rows 8(s-w)+1 .. 8(s-w)+8 and hands the H values of its last column to wave
 // w+1 through LDS (one workgroup barrier per 8 rows).  Nothing per cell goes to memory: the fill keeps only
 //   rowsave  H(64q, *)    every 64th row       (top boundaries of 64-row blocks)
@@ -25,7 +26,7 @@
 namespace ps {
 
 constexpr int SWB = 8;    // rows per pipeline step
-constexpr int SWW = 16;   // waves per workgroup
+constexpr int SWW = 8;    // waves per workgroup: two per SIMD keeps one pair's strips issue-balanced over several CUs
 constexpr bool getenv_nocs = false;
 
 template <int CTRL, int ROWMASK>
@@ -104,12 +105,21 @@ __device__ __forceinline__ unsigned sw_row(int (&G)[K], const int (&c2)[K], cons
     return code;
 }
 
-// ---- fill: grid (pairs), block 1024; one launch per super-strip ------------------------------------------------
+// ---- fill: grid (super-strips, pairs), block 64 * SWW ------------------------------------------------------------------
+// The workgroups of one pair's super-strips run concurrently, as one more level of the row pipeline: the last wave
+// of strip ss stores its boundary column (colsave) and, every 64 rows, publishes the row count with an agent-scope
+// release; the first wave of strip ss+1 acquires it before it reads those rows.  Workgroups are dispatched in
+// blockIdx order (strip index fastest), so a waiting strip's producer is always resident or finished.
+constexpr int SW_SPIN_LIMIT = 1 << 22;
 template <int K>
-__global__ __launch_bounds__(1024) void k_sw_fill(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
-                                                  int* blkmax, int ss) {
-    const SwPair p = pairs[blockIdx.x];
+__global__ __launch_bounds__(64 * SWW) void k_sw_fill(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
+                                                  int* blkmax, int* prog) {
+    const int ss = blockIdx.x;
+    const SwPair p = pairs[blockIdx.y];
     if (p.n1 <= 0 || p.n2 <= 0 || ss * SWW * 64 * K >= p.n2) return;
+    int* prog_my = prog + (int64_t)blockIdx.y * gridDim.x + ss;
+    const bool has_next = (ss + 1) * SWW * 64 * K < p.n2;   // strip ss+1 exists: it consumes this strip's last column
+    int seen = 0;                                           // rows of strip ss-1 known to be complete
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const int gw = ss * SWW + w;
     const int wfirst = gw * 64 * K;            // 0-based first column of the wave
@@ -134,6 +144,13 @@ __global__ __launch_bounds__(1024) void k_sw_fill(const SwPair* pairs, const cha
     auto fetch = [&](int c, int& ch, int& bd) {
         ch = 1; bd = 0;
         const int i0 = c * SWB;
+        if (w == 0 && ss > 0 && c >= 0 && c < nchunks) {   // wave-uniform: the rows of this chunk must have been published
+            const int need = min(p.n1, (i0 + SWB + 63) & ~63);
+            for (int spins = 0; seen < need && spins < SW_SPIN_LIMIT; spins++) {
+                seen = __hip_atomic_load(prog_my - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen < need) __builtin_amdgcn_s_sleep(8);
+            }
+        }
         if (wave_on && c >= 0 && c < nchunks && l < SWB && i0 + l < p.n1) {
             ch = (int)(unsigned char)s1[i0 + l] << 4;
             if (w == 0 && gw > 0) bd = cprev[i0 + 1 + l];
@@ -170,6 +187,8 @@ __global__ __launch_bounds__(1024) void k_sw_fill(const SwPair* pairs, const cha
                 for (int k = 0; k < K; k++) { bm = max(bm, bmk[k] - 8 * k); bmk[k] = 0; }
                 for (int o = 32; o; o >>= 1) bm = max(bm, __shfl_xor(bm, o));
                 if (l == 0) blkmax[p.blk_off + (int64_t)q * p.ngw + gw] = bm;
+                // lane 63 of the strip's last wave stored the boundary column of these rows: release them to strip ss+1
+                if (has_next && w == SWW - 1 && l == 63) __hip_atomic_store(prog_my, iend, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 if (iend < p.n1) {                    // row 64(q+1) is the top boundary of block q+1
                     int* rs = rowsave + p.row_off + (int64_t)(q + 1) * p.pitch + jbase;
 #pragma unroll
@@ -285,9 +304,8 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const char
 
 template <int K>
 static int sw_run(Runtime* rt, hipStream_t st, int np, int nss, const SwPair* d_pairs, const char* d_chars, int* d_row, int* d_col,
-                  int* d_blk, int* d_out, int* d_res) {
-    for (int ss = 0; ss < nss; ss++)
-        hipLaunchKernelGGL(k_sw_fill<K>, dim3(np), dim3(1024), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, ss);
+                  int* d_blk, int* d_prog, int* d_out, int* d_res) {
+    hipLaunchKernelGGL(k_sw_fill<K>, dim3(nss, np), dim3(64 * SWW), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_prog);
     PS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_sw_trace<K>, dim3(np), dim3(64), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res);
     PS_HIP(hipGetLastError());
@@ -305,7 +323,8 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     pairs.assign(np, SwPair());
     int maxn2 = 1;
     for (int k = 0; k < np; k++) maxn2 = std::max(maxn2, (int)in[k].second->size());
-    const int K = maxn2 <= 4096 ? 4 : maxn2 <= 8192 ? 8 : 16;
+    // 4 columns per lane (4096 per workgroup) for short pairs, 8 beyond: a 10 kb pair runs on two workgroups / CUs
+    const int K = maxn2 <= 4096 ? 4 : 8;
     const int sswidth = SWW * 64 * K;
     const int nss = (maxn2 + sswidth - 1) / sswidth;
     int64_t row_tot = 0, col_tot = 0, blk_tot = 0, out_tot = 0;
@@ -331,6 +350,7 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     PS_TRY(rt->buf("sw_row").ensure(row_tot * sizeof(int)));
     PS_TRY(rt->buf("sw_col").ensure(col_tot * sizeof(int)));
     PS_TRY(rt->buf("sw_blk").ensure(blk_tot * sizeof(int)));
+    PS_TRY(rt->buf("sw_prog").ensure((size_t)np * nss * sizeof(int)));
     PS_TRY(rt->buf("sw_out").ensure(out_tot * sizeof(int)));
     PS_TRY(rt->buf("sw_res").ensure((size_t)np * 8 * sizeof(int)));
     SwPair* d_pairs = rt->buf("sw_pairs").as<SwPair>();
@@ -338,6 +358,7 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     int* d_row = rt->buf("sw_row").as<int>();
     int* d_col = rt->buf("sw_col").as<int>();
     int* d_blk = rt->buf("sw_blk").as<int>();
+    int* d_prog = rt->buf("sw_prog").as<int>();
     int* d_out = rt->buf("sw_out").as<int>();
     int* d_res = rt->buf("sw_res").as<int>();
     hipStream_t st = nullptr;
@@ -347,11 +368,11 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     PS_TRY(rt->up(d_chars, pool.data(), pool.size(), st));
     PS_HIP(hipMemsetAsync(d_res, 0, (size_t)np * 8 * sizeof(int), st));
     PS_HIP(hipMemsetAsync(d_blk, 0, blk_tot * sizeof(int), st));   // waves beyond a pair's last column never write theirs
+    PS_HIP(hipMemsetAsync(d_prog, 0, (size_t)np * nss * sizeof(int), st));
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw0, st));
     switch (K) {
-        case 4: PS_TRY(sw_run<4>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res)); break;
-        case 8: PS_TRY(sw_run<8>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res)); break;
-        default: PS_TRY(sw_run<16>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res)); break;
+        case 4: PS_TRY(sw_run<4>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_out, d_res)); break;
+        default: PS_TRY(sw_run<8>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_out, d_res)); break;
     }
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw1, st));
     PS_TRY(rt->hbuf("sw_res").ensure((size_t)np * 8 * sizeof(int)));
