@@ -112,3 +112,26 @@ def test_train_driver_picks_the_most_accurate_parameter_set():
     vp = VaryParams(P)
     assert len(vp) == 16 and all(set(v) == set(P) for v in vp)
     assert all(sum(v[k] != P[k] for k in P) == 3 for v in vp)      # exactly three transition keys move
+
+
+def test_run_regions_in_flight_keeps_order_and_reseeds_per_region():
+    """Single process, worker threads: results come back in region order and the fresh-random-stream hook runs once
+    per region in the worker that refines it (no native library involved)."""
+    import threading
+    from poreseq_amd import dist as psdist
+    seen, lock = [], threading.Lock()
+
+    def fresh():
+        with lock:
+            seen.append(threading.get_ident())
+
+    def process(reg):
+        return "ACGT" * reg, np.arange(3, dtype=np.float64) + reg
+
+    regions = list(range(1, 8))
+    out = psdist.run_regions(regions, process, max_events=4, in_flight=3, fresh_rand=fresh)
+    assert [r[0] for r in out] == ["ACGT" * k for k in regions]
+    assert all(np.array_equal(r[1][:3], np.arange(3) + k) for r, k in zip(out, regions))
+    assert len(seen) == len(regions) and 1 <= len(set(seen)) <= 3
+    seq = psdist.run_regions(regions, process, max_events=4, in_flight=1, fresh_rand=None)
+    assert [r[0] for r in seq] == [r[0] for r in out]
