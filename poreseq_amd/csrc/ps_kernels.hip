@@ -18,15 +18,18 @@
 // 2W + 1 rows, because the band centre is a monotone function of the column; P is sized from the
 // measured footprint, typically ~half the band).  Cell (i, j) needs (i, j-1) = the lane's own
 // previous value, (i-1, j) = the neighbour lane's previous value and (i-1, j-1) = what the neighbour
-// published one step earlier; neighbour values travel through a double-buffered LDS array, one
-// s_barrier per anti-diagonal.  Pipeline per batch of alignments:
+// published one step earlier; neighbour values travel through three rotating LDS buffers, one
+// LDS-only s_barrier per anti-diagonal.  Pipeline per batch of alignments:
 //   k_lb / k_lo   band centres per column, lowest in-band row + footprint per anti-diagonal
 //   k_emis        chip-wide: emission log-densities (three FP64 divisions each) + band flags
-//   k_recur       the serial part: values only (fmax), flag-gated inputs, unconditional stores
+//   k_recur       the serial part: values only (fmax); lanes without a cell hold -infinity, which doubles as the
+//                 reference's implicit zeros / top-row rule, so only two band flags are consulted per cell
+//   k_invfix      (only when a sequence has an invalid 5-mer) zero records of those columns
 //   k_steps       chip-wide: back-pointer codes re-derived with the reference's ordered selection,
 //                 per-column maxima (LDS-aggregated atomics)
 //   k_prefix      running MaxInfo per column, first cell of the global maximum
-//   k_backtrace   LDS-tile walker, then k_updaterefs / k_lb for the new band centres
+//   k_backtrace   LDS-tile walker with wave-wide look-ahead and tile prefetch, then k_fill_like, k_updaterefs /
+//                 k_lb for the new band centres
 //   k_old / k_score / k_reduce   edit scoring (scoreMutation + columnMax) and the per-edit sums
 #include "ps_internal.h"
 
