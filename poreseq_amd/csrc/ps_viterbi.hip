@@ -281,51 +281,60 @@ __device__ __forceinline__ double wave_scan(double v, int lane) {
     return v + add;
 }
 
-// nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131): one 256-thread block per path,
-// thread t owns states 4t .. 4t+3 (so running sums are in state order).  The reference normalises the
+// nkeep stochastic back-traces (randbp, cpp/Viterbi.cpp:105-131): one 512-thread block per path,
+// thread t owns states 2t, 2t+1 (so running sums are in state order).  The reference normalises the
 // 1024 products and walks their running sum until it exceeds r; here the raw running sum is compared
 // with r * total (same choice up to rounding of the forward weights).  grid nkeep.
-__global__ __launch_bounds__(256) void k_vit_trace(const double* __restrict__ lfwd, int T, int start, double skip, double stay,
-                                                  const double* __restrict__ atten, const double* __restrict__ rnd,
-                                                  short* __restrict__ path) {
-    __shared__ double s_wtot[2][4];
-    __shared__ int s_pick[2][4];
+constexpr int VT_THREADS = 512;                 // threads per back-trace
+constexpr int VT_SPT = NS / VT_THREADS;         // consecutive states per thread (2)
+constexpr int VT_WAVES = VT_THREADS / 64;       // 8 waves: two per SIMD, half the per-wave instruction stream of 4 x 4 states
+__global__ __launch_bounds__(VT_THREADS) void k_vit_trace(const double* __restrict__ lfwd, int T, int start, double skip, double stay,
+                                                         const double* __restrict__ atten, const double* __restrict__ rnd,
+                                                         short* __restrict__ path) {
+    __shared__ double s_wtot[2][VT_WAVES];
+    __shared__ int s_pick[2][VT_WAVES];
     const int k = blockIdx.x, t = threadIdx.x, l = t & 63, w = t >> 6;
     const double at = atten[k];
     int cur = start;
-    double4 lf = *(const double4*)(lfwd + (size_t)(T - 1) * NS + 4 * t);
+    double2 lf = *(const double2*)(lfwd + (size_t)(T - 1) * NS + VT_SPT * t);
+    // fwd^atten of this thread's states: independent of the state being traced, so the next row's powers are
+    // computed while this row's scan and barriers are in flight
+    double ex0 = exp(at * lf.x), ex1 = exp(at * lf.y);
     double rcur = rnd[(size_t)k * T];
     for (int i = T - 1; i >= 0; i--) {
         const int par = i & 1;
         if (t == 0) path[(size_t)k * T + i] = (short)cur;
-        double4 nx = lf;
+        double2 nx = lf;
         double rnx = rcur;
-        if (i > 0) { nx = *(const double4*)(lfwd + (size_t)(i - 1) * NS + 4 * t); rnx = rnd[(size_t)k * T + (T - i)]; }
-        double pr[4];
-        const double lv[4] = {lf.x, lf.y, lf.z, lf.w};
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const double tv = trans_weight(cur, 4 * t + m, skip, stay);
-            pr[m] = tv == 0.0 ? 0.0 : tv * exp(at * lv[m]);
-        }
-        const double c0 = pr[0], c1 = c0 + pr[1], c2 = c1 + pr[2], c3 = c2 + pr[3];
-        const double incl = wave_scan(c3, l);
+        if (i > 0) { nx = *(const double2*)(lfwd + (size_t)(i - 1) * NS + VT_SPT * t); rnx = rnd[(size_t)k * T + (T - i)]; }
+        const double tv0 = trans_weight(cur, VT_SPT * t, skip, stay), tv1 = trans_weight(cur, VT_SPT * t + 1, skip, stay);
+        const double c0 = tv0 == 0.0 ? 0.0 : tv0 * ex0;
+        const double c1 = c0 + (tv1 == 0.0 ? 0.0 : tv1 * ex1);
+        const double nex0 = exp(at * nx.x), nex1 = exp(at * nx.y);
+        const double incl = wave_scan(c1, l);
         if (l == 63) s_wtot[par][w] = incl;
         PS_LDS_BARRIER();
-        const double w0 = s_wtot[par][0], w1 = s_wtot[par][1], w2 = s_wtot[par][2], w3 = s_wtot[par][3];
-        const double base = (w == 0 ? 0.0 : w == 1 ? w0 : w == 2 ? w0 + w1 : (w0 + w1) + w2) + (incl - c3);
-        const double thr = rcur * (((w0 + w1) + w2) + w3);
+        double before = 0.0, total = 0.0;   // running sums over the waves in state order
+#pragma unroll
+        for (int q = 0; q < VT_WAVES; q++) {
+            const double wq = s_wtot[par][q];
+            if (q == w) before = total;
+            total = q ? total + wq : wq;
+        }
+        const double base = before + (incl - c1);
+        const double thr = rcur * total;
         int pick = 0x7fffffff;
-        if (thr < base + c3) pick = thr < base + c0 ? 4 * t : thr < base + c1 ? 4 * t + 1 : thr < base + c2 ? 4 * t + 2 : 4 * t + 3;
+        if (thr < base + c1) pick = thr < base + c0 ? VT_SPT * t : VT_SPT * t + 1;
         const unsigned long long hit = __builtin_amdgcn_ballot_w64(pick != 0x7fffffff);
         int wpick = 0x7fffffff;
         if (hit) wpick = __builtin_amdgcn_readlane(pick, __builtin_ctzll(hit));
         if (l == 0) s_pick[par][w] = wpick;
         PS_LDS_BARRIER();
-        const int p0 = s_pick[par][0], p1 = s_pick[par][1], p2 = s_pick[par][2], p3 = s_pick[par][3];
-        const int pk = p0 != 0x7fffffff ? p0 : p1 != 0x7fffffff ? p1 : p2 != 0x7fffffff ? p2 : p3;
+        int pk = 0x7fffffff;
+#pragma unroll
+        for (int q = VT_WAVES - 1; q >= 0; q--) { const int pq = s_pick[par][q]; pk = pq != 0x7fffffff ? pq : pk; }
         cur = pk == 0x7fffffff ? NS - 1 : pk;
-        lf = nx; rcur = rnx;
+        lf = nx; rcur = rnx; ex0 = nex0; ex1 = nex1;
     }
 }
 
@@ -383,7 +392,7 @@ int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const doubl
     PS_TRY(rt->up(rt->buf("vit_att").p, att.data(), nkeep * sizeof(double)));
     PS_HIP(hipMemcpyAsync(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * T * sizeof(double), hipMemcpyHostToDevice, rt->stream));
     hipLaunchKernelGGL(k_vit_log, dim3((unsigned)(((size_t)T * NS + 255) / 256)), dim3(256), 0, rt->stream, d_fwd, (size_t)T * NS);
-    hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(256), 0, rt->stream, d_fwd, T, start, skip, stay,
+    hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(VT_THREADS), 0, rt->stream, d_fwd, T, start, skip, stay,
                        rt->buf("vit_att").as<double>(), rt->buf("vit_rnd").as<double>(), rt->buf("vit_path").as<short>());
     PS_HIP(hipGetLastError());
     prof_end(rt, "viterbi", (double)T * NS * (8.0 * E + 8 + 2 + 8 + 8.0 * nkeep));
