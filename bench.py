@@ -184,6 +184,16 @@ def main():
         a1 = swalign(accs[-1][0], accs[-1][1])[0]
         out["accuracy"] = {"draft_percent": a0, "consensus_percent": a1}
         out.update(pre)
+        # all regions in flight together: HBM-side bytes of one whole schedule (offline PMC sums) x regions per second
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_g_traffic_per_launch.json")) as fh:
+                ws = json.load(fh)["whole_schedule"]
+            if args.length == 10000 and args.events == 10 and "roofline" in out:
+                gbs = (ws["fetch_bytes"] + ws["write_bytes"]) / 1e9 * (value / kb) / world
+                out["roofline"]["aggregate_hbm_gbs_per_gpu"] = gbs
+                out["roofline"]["aggregate_hbm_frac"] = gbs / HBM_PEAK_GBS
+        except (OSError, ValueError, KeyError):
+            pass
 
         # ---- parity spot-check + CPU baseline (oracle / reference: checker and baseline only) ----
         if world == 1:
