@@ -4,7 +4,7 @@
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call it.
 // The shipped library (poreseq_amd/csrc) never links or loads anything from oracle/.
 //
-// Pinning: the restatement is checked (tests/test_oracle_vs_ref.py, tests/golden/*) against
+// Pinning: the restatement is checked (tests/test_oracle.py, tests/golden/*) against
 // the reference's own C++ compiled from /root/reference by oracle/Makefile (oracle/_ref) and
 // against golden vectors produced by the reference's Cython PSAlign (tests/golden/make_golden.py).
 //

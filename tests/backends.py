@@ -8,13 +8,15 @@ from poreseq_amd import _capi
 from poreseq_amd.poreseqcpp import PSAlign, swalign, seqtostates
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "libps_oracle.so")
+ORACLE_SO = os.environ.get("PORESEQ_ORACLE_SO") or os.path.join(ROOT, "oracle", "libps_oracle.so")   # tools/oracle_asan.sh overrides
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libps_ref.so")
 
 _cache = {}
 
 
 def build_oracle():
+    if os.environ.get("PORESEQ_ORACLE_SO"):
+        return
     if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
             os.path.join(ROOT, "oracle", "ps_oracle.cpp")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libps_oracle.so"])

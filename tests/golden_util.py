@@ -45,3 +45,30 @@ def make(cls, z):
     pa.events = events_of(z)
     pa.params = params_of(z)
     return pa
+
+
+# ---- BASELINE-sized fixtures (tests/golden/make_golden_large.py): inputs are regenerated, outputs are stored ----
+def input_digest(draft, events, truth):
+    """SHA-256 over every generated input, in the order make_golden_large.py hashes them."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(draft.encode("ascii")); h.update(b"|"); h.update(truth.encode("ascii"))
+    for ev in events:
+        m = ev.model
+        for a in (ev.mean, ev.stdv, ev.ref_align, ev.ref_like, m.level_mean, m.level_stdv, m.sd_mean, m.sd_stdv):
+            h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        h.update(np.array([m.prob_skip, m.prob_stay, m.prob_extend, m.prob_insert], dtype=np.float64).tobytes())
+        h.update(ev.sequence.encode("ascii"))
+    return h.hexdigest()
+
+
+def regen(z, swalign):
+    """(draft, events, truth, params) of a large fixture, regenerated from its seed with `swalign` (any bit-exact
+    Smith-Waterman: oracle or HIP) and verified against the stored checksum of the reference-side inputs."""
+    from poreseq_amd import synth
+    par = params_of(z)
+    draft, events, truth = synth.make_region(int(z["L"]), int(z["E"]), int(z["seed"]), swalign, par)
+    got = input_digest(draft, events, truth)
+    if got != str(z["input_sha256"]):
+        raise AssertionError("synthetic generator drift: regenerated inputs do not match the fixture's checksum")
+    return draft, events, truth, par

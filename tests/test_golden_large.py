@@ -1,0 +1,74 @@
+"""BASELINE-sized golden vectors from the real reference (tests/golden/make_golden_large.py):
+
+  score10k_E10 / score10k_E30   ScoreEvents + ScoreMutations (2000 point + 20 multi-base edits, scoring_width 100 and 20)
+                                on a 10 kb region with 10 / 30 events (config #2 / one region of config #3)
+  consensus_L1000/L1500/L3000   the full Mutate.py schedule (per-call nbases, the sequence after every call, final
+                                ref_align / ref_like of every event, final ScoreEvents)
+
+Inputs are regenerated from the fixture's seed and verified by checksum; every comparison is bit-exact (tolerance 0).
+The oracle runs the cheaper cases on CPU (`not gpu`); the HIP library runs all of them (`gpu`).
+"""
+import copy
+
+import numpy as np
+import pytest
+
+import backends as B
+import golden_util as G
+from poreseq_amd.poreseqcpp import PSAlign, swalign
+
+
+def _score_case(cls, sw, name, tags=("sw100", "sw20")):
+    z = G.load(name)
+    draft, events, truth, par = G.regen(z, sw)
+    mk = lambda p: B.make_pa(cls, draft, copy.deepcopy(events), p)
+    assert np.array_equal(np.array(mk(par).ScoreEvents()), z["ScoreEvents"])
+    muts = G.muts_of(z)
+    for tag in tags:
+        p = dict(par, scoring_width=100.0 if tag == "sw100" else 20.0)
+        got = mk(p).ScoreMutations(muts)
+        want = z["ScoreMutations_" + tag]
+        assert np.array_equal(np.array([g.score for g in got]), want), (name, tag)
+
+
+def _schedule_case(cls, sw, name):
+    z = G.load(name)
+    draft, events, truth, par = G.regen(z, sw)
+    B.reset_rand()
+    pa = B.make_pa(cls, draft, copy.deepcopy(events), par)
+    for call, nb, seq in zip(z["calls"], z["nbases"], z["sequences"]):
+        call = str(call)
+        if call == "Mutate:self":
+            got = pa.Mutate(reps=4)
+        elif call == "Mutate:viterbi":
+            got = pa.Mutate(seqs="viterbi")
+        else:
+            got = pa.Refine()
+        assert got == int(nb), (name, call)
+        assert pa.sequence == str(seq), (name, call)
+    for e, ev in enumerate(pa.events):
+        assert np.array_equal(ev.ref_align, z["final_ev%d_ref_align" % e]), (name, e)
+        assert np.array_equal(ev.ref_like, z["final_ev%d_ref_like" % e]), (name, e)
+    assert np.array_equal(np.array(pa.ScoreEvents()), z["final_ScoreEvents"])
+
+
+# ---- CPU: the oracle against the reference's vectors (pins the oracle at sizes where the band is narrower than the columns)
+def test_oracle_score10k_E10_golden():
+    _score_case(B.OraclePSAlign, B.oracle_swalign, "score10k_E10", tags=("sw20",))
+
+
+def test_oracle_consensus_L1000_golden():
+    _schedule_case(B.OraclePSAlign, B.oracle_swalign, "consensus_L1000")
+
+
+# ---- GPU: the HIP library against the same vectors -------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["score10k_E10", "score10k_E30"])
+def test_hip_score10k_golden(name):
+    _score_case(PSAlign, swalign, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["consensus_L1000", "consensus_L1500", "consensus_L3000"])
+def test_hip_consensus_schedule_golden(name):
+    _schedule_case(PSAlign, swalign, name)

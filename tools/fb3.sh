@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/fb3 -o r -- python3 $GRAFT_REPO_ROOT/tests/gpu_fillbench.py 2>&1 | grep -i "score mode\|RW="
+rocprofv3 --kernel-trace --output-format csv -d /tmp/fb3 -o r -- python3 $GRAFT_REPO_ROOT/tools/gpu_fillbench.py 2>&1 | grep -i "score mode\|RW="
 python3 - $(find /tmp/fb3 -name '*kernel_trace.csv' | head -1) <<'PY'
 import csv, sys, collections
 d = collections.defaultdict(list)

@@ -1,7 +1,7 @@
 """One-off validation (minutes of CPU): the full stochastic consensus schedule on a 3 kb / 10-event region, HIP vs the
 CPU oracle, every intermediate sequence compared (not part of the suite: the oracle is O(L^2))."""
 import copy, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np
 import backends as B
 from poreseq_amd import synth

@@ -1,6 +1,6 @@
 """Ad-hoc GPU parity sweep (HIP vs oracle) used during bring-up; the pytest suite supersedes it."""
 import copy, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from backends import OraclePSAlign, oracle_api, oracle_swalign, make_pa

@@ -1,7 +1,7 @@
 # total HBM-side bytes of one consensus run (two rocprofv3 passes: FETCH_SIZE, WRITE_SIZE); prints per-kernel sums
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o r -- python3 $GRAFT_REPO_ROOT/tests/gpu_onerun.py > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o r -- python3 $GRAFT_REPO_ROOT/tools/gpu_onerun.py > /tmp/pmc_$c.log 2>&1
   tail -1 /tmp/pmc_$c.log
   f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
   python3 - "$f" "$c" <<'PY'

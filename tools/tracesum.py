@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise PORESEQ_TRACE output of tests/gpu_hostprof.py (measured run only)."""
+"""Summarise PORESEQ_TRACE output of tools/gpu_hostprof.py (measured run only)."""
 import re, sys, collections
 for fn in sys.argv[1:]:
     txt = open(fn).read()
