@@ -8,12 +8,11 @@ namespace ps {
 // Alignment::update (cpp/Alignment.cpp:63-73) for one event, then un-skew the device matrices.
 int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* stay, uint8_t* sm, uint8_t* ss) {
     std::vector<JobSpec> specs(1);
-    specs[0].ev = ev; specs[0].states = &a->states;
+    specs[0].a = a; specs[0].ev = ev; specs[0].states = &a->states; specs[0].out = a->d_out + ev;
     specs[0].ra = a->d_ra + a->off[ev]; specs[0].rl = a->d_rl + a->off[ev]; specs[0].ri = a->d_ri + a->off[ev];
     Batch b;
-    PS_TRY(b.build(rt, a, specs, 2, 0));
-    b.d.out = a->d_out + ev;
-    PS_TRY(realign(rt, a, b, 0));
+    PS_TRY(b.build(rt, specs, 2, 0));
+    PS_TRY(realign(rt, b));
     a->host_refs_valid = false;
     const JobD& J = b.jobs[0];
     const int n0 = J.n0, C = J.C, P = J.P;

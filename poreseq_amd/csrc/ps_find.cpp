@@ -118,20 +118,20 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             for (size_t q = q0; q < q1; q++)
                 for (int e = 0; e < a->E; e++) {
                     JobSpec s;
-                    s.ev = e; s.states = &sstates[q];
+                    s.a = a; s.ev = e; s.states = &sstates[q];
                     const size_t o = (q - q0) * a->ntot + a->off[e];
                     s.ra = d_ra + o; s.rl = d_rl + o; s.ri = d_ri + o;
                     specs.push_back(s);
                 }
             DBuf& ob = rt->buf("seed_out");
-            PS_TRY(ob.ensure(specs.size() * sizeof(JobOut)));
+            PS_TRY(ob.ensure(specs.size() * sizeof(JobOut)));   // (before the out pointers are taken: ensure() may move the buffer)
             PS_HIP(hipMemsetAsync(ob.p, 0, specs.size() * sizeof(JobOut), rt->stream));
+            for (size_t k = 0; k < specs.size(); k++) specs[k].out = ob.as<JobOut>() + k;
             Batch b;
-            PS_TRY(b.build(rt, a, specs, 1, 0));
-            b.d.out = ob.as<JobOut>();
+            PS_TRY(b.build(rt, specs, 1, 0));
             PS_TRY(launch_updaterefs(rt, b.d));  // MapAlignments ends with updaterefs (cpp/EventUtil.cpp:51)
             tk.lap("seed batch build");
-            PS_TRY(realign(rt, a, b, 0));
+            PS_TRY(realign(rt, b));
             PS_HIP(hipStreamSynchronize(rt->stream));
             tk.lap("seed realign");
             double *r_ra = nullptr, *r_rl = nullptr;

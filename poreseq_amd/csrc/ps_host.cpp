@@ -215,62 +215,72 @@ std::string apply_edit(const std::string& b, const Mut& m) {
 }
 
 // ------------------------------------------------------------------------------------------ batch
-int Batch::build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int ndir_, int lb_extra, bool matrices) {
-    (void)matrices;
+int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int lb_extra) {
     ndir = ndir_;
-    const int W = a->par.realign_width;
-    if (W < 0) return fail(PS_ERR_BAD_ARG, "realign_width < 0");
-    Pmax = std::max(64, ((2 * W + 3 + 63) / 64) * 64);   // widest possible footprint 2W + 1, plus the two idle slots k_recur relies on
-    if (Pmax > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 510: band wider than one workgroup");
-    P = 0;
+    P = 0; Pmax = 64;
     jobs.clear();
     maxS = 0; maxC = 0; maxn = 0; maxlbn = 0;
+    constexpr int ST_PAD = 8;   // ints of -1 around every state list: k_fill fetches four states per 16-byte load
     int64_t st_tot = 0, lb_tot = 0, lo_tot = 0, col_tot = 0;
     std::vector<int> h_states;
     std::map<const std::vector<int>*, int64_t> st_seen;
-    for (const JobSpec& s : specs) {
+    std::vector<int64_t> st_at(specs.size());
+    for (size_t k = 0; k < specs.size(); k++) {
+        const JobSpec& s = specs[k];
+        const Align* a = s.a;
+        const int W = a->par.realign_width;
+        if (W < 0) return fail(PS_ERR_BAD_ARG, "realign_width < 0");
+        // widest possible footprint 2W + 1, plus the idle slots k_fill wants between two rows of a lane
+        const int pm = std::max(64, ((2 * W + 6 + 63) / 64) * 64);
+        if (pm > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 509: band wider than one workgroup");
+        Pmax = std::max(Pmax, pm);
         JobD j;
         memset(&j, 0, sizeof(j));
-        j.ev = s.ev; j.n0 = a->n[s.ev]; j.C = (int)s.states->size(); j.W = W; j.P = 0;
+        j.mean = a->d_mean + a->off[s.ev]; j.stdv = a->d_stdv + a->off[s.ev]; j.lsd = a->d_lsd + a->off[s.ev];
+        j.model = a->d_model + (size_t)s.ev * 6 * NS;
+        j.lsk = a->h_trans[s.ev * 4 + 0]; j.lst = a->h_trans[s.ev * 4 + 1]; j.lex = a->h_trans[s.ev * 4 + 2]; j.lin = a->h_trans[s.ev * 4 + 3];
+        j.lik_offset = a->par.lik_offset;
+        j.n0 = a->n[s.ev]; j.C = (int)s.states->size(); j.W = W; j.P = 0;
         j.force_inert = (W == 0) ? 1 : 0;
         j.lbn = j.C + 2 + lb_extra;
-        j.lev_off = a->off[s.ev];
         auto it = st_seen.find(s.states);
         if (it == st_seen.end()) {
-            st_seen[s.states] = st_tot; j.st_off = st_tot;
+            h_states.insert(h_states.end(), ST_PAD, -1);
+            st_seen[s.states] = st_tot + ST_PAD; st_at[k] = st_tot + ST_PAD;
             h_states.insert(h_states.end(), s.states->begin(), s.states->end());
-            st_tot += j.C;
-        } else j.st_off = it->second;
+            h_states.insert(h_states.end(), ST_PAD, -1);
+            st_tot += j.C + 2 * ST_PAD;
+        } else st_at[k] = it->second;
         j.lb_off = lb_tot; lb_tot += j.lbn;
         j.lbn_off = lb_tot; lb_tot += j.lbn;
         j.S = (int64_t)j.n0 + j.C + 1;
         for (int d = 0; d < ndir; d++) {
-            j.lo_off[d] = lo_tot; lo_tot += j.S;
+            j.lo_off[d] = lo_tot; lo_tot += j.S + LO_PAD;
             j.col_off[d] = col_tot; col_tot += j.C + 1;
         }
-        j.ra = s.ra; j.rl = s.rl; j.ri = s.ri;
+        j.ra = s.ra; j.rl = s.rl; j.ri = s.ri; j.out = s.out;
         maxS = std::max(maxS, j.S); maxC = std::max(maxC, j.C); maxn = std::max(maxn, j.n0); maxlbn = std::max(maxlbn, j.lbn);
         jobs.push_back(j);
     }
     ncols = col_tot;
-    has_invalid = false;
-    for (int v : h_states) if (v < 0) { has_invalid = true; break; }
-    PS_TRY(rt->buf("jobs").ensure(jobs.size() * sizeof(JobD)));
+    PS_TRY(rt->buf("jobs").ensure(std::max<size_t>(jobs.size(), 1) * sizeof(JobD)));
     PS_TRY(rt->buf("states").ensure(std::max<size_t>(h_states.size(), 1) * sizeof(int)));
     PS_TRY(rt->buf("lb").ensure(std::max<int64_t>(lb_tot, 1) * sizeof(int)));
     PS_TRY(rt->buf("lo").ensure(std::max<int64_t>(lo_tot, 1) * sizeof(int)));
+    PS_TRY(rt->buf("hi").ensure(std::max<int64_t>(lo_tot, 1) * sizeof(int)));
     PS_TRY(rt->buf("cmax").ensure(std::max<int64_t>(col_tot, 1) * sizeof(double)));
     PS_TRY(rt->buf("pm").ensure(std::max<int64_t>(col_tot, 1) * sizeof(double)));
+    PS_TRY(rt->buf("maxw").ensure(64));
+    const int* d_states = rt->buf("states").as<int>();
+    for (size_t k = 0; k < jobs.size(); k++) jobs[k].st = d_states + st_at[k];
     PS_TRY(rt->up(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD)));
     PS_TRY(rt->up(rt->buf("states").p, h_states.data(), h_states.size() * sizeof(int)));
     d.jobs = rt->buf("jobs").as<JobD>();
     d.njobs = (int)jobs.size();
-    d.mean = a->d_mean; d.stdv = a->d_stdv; d.logstdv = a->d_lsd; d.model = a->d_model; d.trans = a->d_trans;
-    d.states = rt->buf("states").as<int>();
-    d.lb = rt->buf("lb").as<int>(); d.lo = rt->buf("lo").as<int>();
-    d.rec = nullptr; d.em = nullptr; d.flg = nullptr;
+    d.lb = rt->buf("lb").as<int>(); d.lo = rt->buf("lo").as<int>(); d.hi = rt->buf("hi").as<int>();
+    d.rec = nullptr; d.flg = nullptr;
     d.cmax = rt->buf("cmax").as<double>(); d.pm = rt->buf("pm").as<double>();
-    d.lik_offset = a->par.lik_offset;
+    d.maxw = rt->buf("maxw").as<int>();
     d.log2pi = std::log(2 * M_PI);  // cpp/AlignUtil.h:24
     return PS_OK;
 }
@@ -282,28 +292,24 @@ int Batch::place(Runtime* rt, int P_) {
     int64_t mat_tot = 0;
     for (JobD& j : jobs) {
         j.P = P;
-        // + 8 spare anti-diagonals (REC_PAD): zero flags from k_emis, touched by k_recur's padded last prefetch groups
-        for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot; mat_tot += (j.S + 8) * P; }
+        // spare anti-diagonals in front of and behind every matrix: k_fill's pipeline starts early and runs past S
+        for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot + (int64_t)MAT_FRONT * P; mat_tot += (j.S + MAT_FRONT + MAT_BACK) * P; }
     }
     cells = mat_tot;
     PS_TRY(rt->buf("rec").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double2)));
-    PS_TRY(rt->buf("em").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double)));
     PS_TRY(rt->buf("flg").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short)));
-    PS_TRY(rt->buf("dummy").ensure(jobs.size() * ndir * 1024 * sizeof(double2)));
-    d.dummy = rt->buf("dummy").as<double2>();
     PS_TRY(rt->up(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD)));
-    d.rec = rt->buf("rec").as<double2>(); d.em = rt->buf("em").as<double>(); d.flg = rt->buf("flg").as<unsigned short>();
+    d.rec = rt->buf("rec").as<double2>(); d.flg = rt->buf("flg").as<unsigned short>();
     return PS_OK;
 }
 
 // bytes the fills of this batch move by the SURVEY 8(d) accounting: 18 B (fwd) / 16 B (back) per band cell
-double Batch::fill_alg_bytes(const Align* a) const {
+double Batch::fill_alg_bytes() const {
     double t = 0;
     for (const JobD& j : jobs) {
         const double band = std::min<double>(2.0 * j.W + 1, j.n0);
         t += (double)j.C * band * (ndir == 2 ? 34.0 : 18.0) + 24.0 * j.n0 * ndir;
     }
-    (void)a;
     return t;
 }
 
@@ -347,6 +353,7 @@ int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_event
         for (int k = 0; k < 4; k++) tr[e * 4 + k] = std::log(trans[e * 4 + k]);
     }
     h_model = mdl;
+    h_trans = tr;
     // one slab: mean, stdv, lsd, ra, rl, ri [ntot each] | model | trans | out
     const size_t nlev = (size_t)std::max<int64_t>(ntot, 1);
     const size_t bytes = 6 * nlev * sizeof(double) + (mdl.size() + tr.size() + 2) * sizeof(double) +
@@ -373,21 +380,20 @@ int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_event
     PS_HIP(hipStreamSynchronize(rt->stream));
     // EventData::setData ends with updaterefs() (cpp/EventData.h:223)
     Batch b;
-    PS_TRY(base_batch(rt, &b, 1, 0, false));
+    PS_TRY(base_batch(rt, &b, 1, 0));
     PS_TRY(launch_updaterefs(rt, b.d));
     PS_HIP(hipStreamSynchronize(rt->stream));
     return PS_OK;
 }
 
-int Align::base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra, bool matrices) {
+int Align::base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra) {
     std::vector<JobSpec> specs(E);
     for (int e = 0; e < E; e++) {
-        specs[e].ev = e; specs[e].states = &states;
+        specs[e].a = this; specs[e].ev = e; specs[e].states = &states;
         specs[e].ra = d_ra + off[e]; specs[e].rl = d_rl + off[e]; specs[e].ri = d_ri + off[e];
+        specs[e].out = d_out + e;
     }
-    PS_TRY(b->build(rt, this, specs, ndir, lb_extra, matrices));
-    b->d.out = d_out;
-    return PS_OK;
+    return b->build(rt, specs, ndir, lb_extra);
 }
 
 int Align::refs_to_host(Runtime* rt) {
@@ -404,20 +410,19 @@ int Align::refs_to_host(Runtime* rt) {
 
 // forward fill + backtrace + updaterefs of a batch (the body of ScoreAlignments per event,
 // cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
-int realign(Runtime* rt, Align* a, Batch& b, int lb_extra_ready) {
-    (void)lb_extra_ready;
+int realign(Runtime* rt, Batch& b) {
     if (!b.d.njobs) return PS_OK;
     PS_TRY(launch_begin(rt, b.d));
     PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
     PS_TRY(launch_lo(rt, b.d, b.ndir, b.maxS));
-    JobOut* o = nullptr;
-    PS_TRY(rt->down(&o, b.d.out, (size_t)b.d.njobs));
+    int* w = nullptr;
+    PS_TRY(rt->down(&w, b.d.maxw, (size_t)1));
     PS_HIP(hipStreamSynchronize(rt->stream));
-    int w = 1;
-    for (int k = 0; k < b.d.njobs; k++) w = std::max(w, o[k].maxw);
-    PS_TRY(b.place(rt, w + 2));   // two slots more than the widest footprint: every lane idles between two rows (k_recur)
-    if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes(a);
-    PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P, b.ncols, b.has_invalid));
+    // five slots more than the widest footprint: a lane idles at least four anti-diagonals between two rows, so a
+    // four-step prefetch window of k_fill never spans two rows of a lane that has a cell
+    PS_TRY(b.place(rt, std::max(*w, 1) + 5));
+    if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes();
+    PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P, b.ncols));
     PS_TRY(launch_backtrace(rt, b.d, b.maxn));
     PS_TRY(launch_updaterefs(rt, b.d));
     return PS_OK;
@@ -428,7 +433,7 @@ int score_alignments(Runtime* rt, Align* a, double* scores, double* likes) {
     if (!a->E) return PS_OK;
     Batch b;
     PS_TRY(a->base_batch(rt, &b, 1, 0));
-    PS_TRY(realign(rt, a, b, 0));
+    PS_TRY(realign(rt, b));
     a->host_refs_valid = false;
     JobOut* out = nullptr;
     PS_TRY(rt->down(&out, a->d_out, (size_t)a->E));
@@ -518,7 +523,7 @@ int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::ve
     tk.lap("edit sizes");
     Batch b;
     PS_TRY(a->base_batch(rt, &b, 2, extra));
-    PS_TRY(realign(rt, a, b, extra));
+    PS_TRY(realign(rt, b));
     a->host_refs_valid = false;
     tk.lap("realign enqueue");
     std::vector<int> h_states((size_t)M * ncolmax, -1);

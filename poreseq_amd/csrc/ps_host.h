@@ -21,9 +21,11 @@ void rand_seed(unsigned seed);   // per-thread generator of ViterbiMutate's devi
 int rand_next();
 
 struct JobSpec {
+    Align* a = nullptr;                                  // owner of the event data (one batch may mix several AlignData)
     int ev = 0;
     const std::vector<int>* states = nullptr;
     double *ra = nullptr, *rl = nullptr, *ri = nullptr;  // device arrays of the job
+    JobOut* out = nullptr;                               // device result record of the job
 };
 
 // a set of alignment jobs with all their device workspaces carved out of the runtime pool
@@ -32,10 +34,9 @@ struct Batch {
     BatchD d;
     int ndir = 1, P = 0, Pmax = 64, maxC = 0, maxn = 0, maxlbn = 0;
     int64_t maxS = 0, cells = 0, ncols = 0;
-    bool has_invalid = false;   // some job's sequence has an invalid 5-mer (state -1)
-    int build(Runtime* rt, Align* a, const std::vector<JobSpec>& specs, int ndir, int lb_extra, bool matrices = true);
+    int build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir, int lb_extra);
     int place(Runtime* rt, int P);
-    double fill_alg_bytes(const Align* a) const;
+    double fill_alg_bytes() const;
 };
 
 // AlignData (cpp/AlignData.h:26-35) with the event data resident in HBM
@@ -48,7 +49,7 @@ struct Align {
     std::vector<int64_t> off;
     int64_t ntot = 0;
     std::vector<std::string> evseqs;
-    std::vector<double> h_mean, h_stdv, h_ra, h_rl, h_model;
+    std::vector<double> h_mean, h_stdv, h_ra, h_rl, h_model, h_trans;   // h_trans: log transition probabilities [E][4]
     bool host_refs_valid = true;
     void* slab = nullptr;
     double *d_mean = nullptr, *d_stdv = nullptr, *d_lsd = nullptr, *d_ra = nullptr, *d_rl = nullptr, *d_ri = nullptr;
@@ -61,7 +62,7 @@ struct Align {
                const double* mean, const double* stdv, const double* ref_align, const double* ref_like,
                const double* model, const double* trans, const char* evseq, const int64_t* evseq_off,
                const ps_params* params);
-    int base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra, bool matrices = true);
+    int base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra);
     int refs_to_host(Runtime* rt);
 };
 
@@ -69,7 +70,7 @@ std::vector<int> states_of(const std::string& bases);
 std::string apply_edit(const std::string& b, const Mut& m);
 void accumulate_likes(const double* ra, const double* rl, int n, int C, double* likes);
 
-int realign(Runtime* rt, Align* a, Batch& b, int);
+int realign(Runtime* rt, Batch& b);
 int score_alignments(Runtime* rt, Align* a, double* scores, double* likes);
 int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::vector<Mut>* out);
 void find_point_mutations(const Align* a, std::vector<Mut>* out);

@@ -5,10 +5,9 @@
 //   models      per event 6 x 1024 f64: lev_mean, lev_stdv, log_lev, sd_mean, sd_lambda, log_lambda
 //   refs        per alignment job ref_align / ref_like / ref_index f64[n0]   (rewritten by the backtrace)
 //   DP matrices per (job, direction): "skewed" storage  REC[s][slot], s = i + j (anti-diagonal),
-//               slot = i mod P, one 16-byte record {main, stay} per cell, plus FLG[s][slot] u16
-//               (band flags before the recurrence pass, {main step, stay step} after it).
-//               One anti-diagonal is one contiguous run of P records: the recurrence kernel's
-//               loads and stores are fully coalesced.
+//               slot = i mod P, one 16-byte record {main, stay} per cell, plus (forward) FLG[s][slot] u16
+//               = {main step, stay step, score <= 0 bits}.  One anti-diagonal is one contiguous run of
+//               P records: the fill kernel's stores are fully coalesced.
 #ifndef PS_INTERNAL_H_
 #define PS_INTERNAL_H_
 
@@ -110,26 +109,33 @@ struct Mut {
 };
 
 // ---- device-side job descriptor: one (event, sequence) alignment ---------------------------
+// Everything a kernel needs about a job hangs off the descriptor itself (device pointers into the owning
+// AlignData's slab), so one batch can mix jobs of several AlignData handles (regions refined in lock-step).
+struct JobOut;
 struct JobD {
-    int ev;          // event index (model / transition rows)
+    const double* mean;   // levels of the job's event  [n0]
+    const double* stdv;
+    const double* lsd;    // log(stdv), host libm
+    const double* model;  // derived model of the event, [6][1024]: lev_mean, lev_stdv, log_lev, sd_mean, sd_lambda, log_lambda
+    const int* st;        // 5-mer states of the job's sequence [C] (4 ints of -1 padding on either side)
+    double lsk, lst, lex, lin;   // log transition probabilities: skip, stay, extend, insert
+    double lik_offset;
     int n0;          // levels in the event
     int C;           // states of the job's sequence
     int W;           // realign_width (band half-width of the fills)
     int force_inert; // realign_width == 0: every Alignment is a no-op (cpp/Alignment.cpp:85-86)
-    int P;           // slots per anti-diagonal (multiple of 64, >= 2W+1)
+    int P;           // slots per anti-diagonal (multiple of 64, >= widest footprint + 5)
     int lbn;         // entries in each lb table (C + 2 + extra)
-    int pad0;
-    int64_t lev_off;     // into mean/stdv/logstdv
-    int64_t st_off;      // into the states pool
     int64_t lb_off;      // lb table the fills were made with          (int32[lbn])
     int64_t lbn_off;     // lb table after the latest backtrace        (int32[lbn])
-    int64_t mat_off[2];  // record offset of the forward / backward matrix
-    int64_t lo_off[2];   // into LO (int32 per anti-diagonal)
+    int64_t mat_off[2];  // record offset of anti-diagonal 0 of the forward / backward matrix
+    int64_t lo_off[2];   // into LO / HI (int32 per anti-diagonal)
     int64_t col_off[2];  // into per-column arrays (C+1 entries per direction)
     int64_t S;           // anti-diagonals: n0 + C + 1
     double* ra;          // ref_align  [n0]
     double* rl;          // ref_like   [n0]
     double* ri;          // ref_index  [n0]
+    JobOut* out;         // per job results (persist in the AlignData between calls for its own events)
 };
 
 // per job results living in device memory
@@ -139,28 +145,25 @@ struct JobOut {
     int has_index;    // ref_index non-empty after the latest updaterefs
     int refstart, refend;
     int inert;        // latched at the start of an API call: the reference's stripe_width == 0
-    int maxw;         // widest band footprint on one anti-diagonal (sizes P)
-    int pad;
+    int pad0, pad1;
 };
 
-// device pointers of everything a batch of jobs needs (filled by Batch::upload)
+constexpr int MAT_FRONT = 8;   // spare anti-diagonals in front of every matrix (the fill pipeline starts 8 steps early)
+constexpr int MAT_BACK = 16;   // and behind it (the last loop body runs past S)
+constexpr int LO_PAD = 32;     // LO / HI entries behind S, all -1
+
+// device pointers of the pools a batch of jobs lives in (filled by Batch::build / place)
 struct BatchD {
     const JobD* jobs;
-    JobOut* out;
     int njobs;
-    const double *mean, *stdv, *logstdv;  // concatenated levels
-    const double* model;                  // [E][6][1024]
-    const double* trans;                  // [E][4] log probabilities: skip, stay, extend, insert
-    const int* states;                    // pool
     int* lb;                              // pool of lb tables
-    int* lo;                              // pool
-    double2* rec;                         // matrices {main, stay}
-    double* em;                           // emission log-densities, same skewed layout
-    double2* dummy;                       // 1024 scratch records per workgroup: store target of lanes without a cell
-    unsigned short* flg;
+    int* lo;                              // lowest in-band row per anti-diagonal (-1: none)
+    int* hi;                              // highest in-band row per anti-diagonal
+    double2* rec;                         // matrices {main, stay}, skewed
+    unsigned short* flg;                  // forward matrices: step words {main step, stay step << 8, score <= 0 bits}
     double* cmax;                         // per column max of main
     double* pm;                           // prefix max over columns (MaxInfo.score per column)
-    double lik_offset;
+    int* maxw;                            // widest band footprint of any job of the batch on one anti-diagonal (sizes P)
     double log2pi;
 };
 
@@ -168,7 +171,7 @@ struct BatchD {
 int launch_updaterefs(Runtime* rt, const BatchD& b);
 int launch_lb(Runtime* rt, const BatchD& b, int which /*0: lb_off, 1: lbn_off*/, int maxlbn);
 int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS);
-int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols, bool has_invalid);
+int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols);
 int launch_backtrace(Runtime* rt, const BatchD& b, int maxn);
 
 struct ScoreArgs {

@@ -16,17 +16,10 @@
 // s = 2 .. n0 + C; lane `slot` owns the row i == slot (mod P) that is inside the band on that
 // anti-diagonal (the band's footprint on one anti-diagonal is a contiguous run of at most
 // 2W + 1 rows, because the band centre is a monotone function of the column; P is sized from the
-// measured footprint, typically ~half the band).  Cell (i, j) needs (i, j-1) = the lane's own
-// previous value, (i-1, j) = the neighbour lane's previous value and (i-1, j-1) = what the neighbour
-// published one step earlier; neighbour values travel through three rotating LDS buffers, one
-// LDS-only s_barrier per anti-diagonal.  Pipeline per batch of alignments:
-//   k_lb / k_lo   band centres per column, lowest in-band row + footprint per anti-diagonal
-//   k_emis        chip-wide: emission log-densities (three FP64 divisions each) + band flags
-//   k_recur       the serial part: values only (fmax); lanes without a cell hold -infinity, which doubles as the
-//                 reference's implicit zeros / top-row rule, so only two band flags are consulted per cell
-//   k_invfix      (only when a sequence has an invalid 5-mer) zero records of those columns
-//   k_steps       chip-wide: back-pointer codes re-derived with the reference's ordered selection,
-//                 per-column maxima (LDS-aggregated atomics)
+// measured footprint, typically ~half the band).  Pipeline per batch of alignments:
+//   k_lb / k_lo   band centres per column; lowest / highest in-band row + footprint per anti-diagonal
+//   k_fill        emissions, band flags, recurrence, back-pointer codes and column maxima in one sweep
+//                 (one 16-byte record + one 2-byte step word per cell leave the chip; nothing is re-read)
 //   k_prefix      running MaxInfo per column, first cell of the global maximum
 //   k_backtrace   LDS-tile walker with wave-wide look-ahead and tile prefetch, then k_fill_like, k_updaterefs /
 //                 k_lb for the new band centres
@@ -35,8 +28,6 @@
 
 namespace ps {
 
-enum : unsigned { F_ACT = 1, F_VL = 2, F_VD = 4, F_TOP = 8, F_BLANK = 32,
-                  F_RD = 128 /* the diagonal neighbour's value counts (see recur_step) */ };
 constexpr unsigned FLG_DEAD = 0xC000u;   // final step word of a cell in an invalid-5-mer column: both scores <= 0, no move
 enum : unsigned { M_SKIP = 0, M_MATCH = 1, M_INSERT = 2, M_IGNORE = 3, M_STAY = 4, M_EXTEND = 5, M_IMPL = 255 };
 
@@ -84,7 +75,7 @@ __device__ __forceinline__ double emission(const ModelRow& m, double x, double s
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_updaterefs(BatchD b) {
     const JobD& J = b.jobs[blockIdx.x];
-    JobOut* O = b.out + blockIdx.x;
+    JobOut* O = J.out;
     const int n = J.n0, tid = threadIdx.x;
     const double* __restrict__ ra = J.ra;
     double* __restrict__ ri = J.ri;
@@ -138,25 +129,28 @@ __global__ void k_lb(BatchD b, int which) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= J.lbn) return;
     int* lb = b.lb + (which ? J.lbn_off : J.lb_off);
-    lb[j] = b.out[blockIdx.y].has_index ? lower_bound_d(J.ri, J.n0, j) : -1;
+    lb[j] = J.out->has_index ? lower_bound_d(J.ri, J.n0, j) : -1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// lo[s]: lowest in-band row on anti-diagonal s (-1: none) and the footprint width of the band on s.
+// lo[s] / hi[s]: lowest and highest in-band row on anti-diagonal s (-1: none).
 // The columns present on s are those with i0(j) + j <= s <= i1(j) + j — a contiguous range
-// [jlo, jhi] because both bounds are strictly increasing in j; rows are s - j, so lo = s - jhi and
-// width = jhi - jlo + 1 <= 2W + 1.  The per-job maximum width sizes P (slots per anti-diagonal).
+// [jlo, jhi] because both bounds are strictly increasing in j; rows are s - j, so lo = s - jhi,
+// hi = s - jlo and the footprint hi - lo + 1 <= 2W + 1.  The per-job maximum footprint sizes P.
+// Consecutive non-empty anti-diagonals move each end by at most one row (jhi and jlo grow by at most one per
+// step), which is what lets k_fill derive every band flag from these two numbers and the lane's own history.
+// Entries [S, S + LO_PAD) are -1: the fill pipeline looks a few anti-diagonals past the end.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lo(BatchD b, int ndir) {
     const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
-    if (b.out[job].inert) return;
+    if (J.out->inert) return;
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int width = 0;
-    if (s < J.S) {
+    if (s < J.S + LO_PAD) {
         const int* lb = b.lb + J.lb_off;
-        int res = -1;
-        if (J.C >= 1) {
+        int res = -1, top = -1;
+        if (J.C >= 1 && s < J.S) {
             int i0, i1;
             band_of(lb, dir, 1, J.C, J.n0, J.W, i0, i1);
             if (i0 + 1 <= s) {
@@ -175,109 +169,52 @@ __global__ __launch_bounds__(256) void k_lo(BatchD b, int ndir) {
                         band_of(lb, dir, mid, J.C, J.n0, J.W, i0, i1);
                         if ((int64_t)i1 + mid >= s) hi = mid; else lo = mid + 1;
                     }
-                    if (lo <= jhi) { res = (int)(s - jhi); width = jhi - lo + 1; }
+                    if (lo <= jhi) { res = (int)(s - jhi); top = (int)(s - lo); width = jhi - lo + 1; }
                 }
             }
         }
         (b.lo + J.lo_off[dir])[s] = res;
+        (b.hi + J.lo_off[dir])[s] = top;
     }
     for (int off = 32; off; off >>= 1) width = max(width, __shfl_xor(width, off));
-    if ((threadIdx.x & 63) == 0 && width > 0) atomicMax(&b.out[job].maxw, width);
+    if ((threadIdx.x & 63) == 0 && width > 0) atomicMax(b.maxw, width);   // one P for the whole batch
 }
 
 // ------------------------------------------------------------------------------------------------
-// emission pass: for every (s, slot) write EM = emission (or 0) and FLG = band flags
-// grid (nblk, njobs*ndir), block 1024 (16 waves share the event's 48 KB model in LDS: two blocks per CU give full
-// occupancy).  The work unit is one wave-wide run of 64 slots of one anti-diagonal; every wave walks a contiguous
-// range of units, so the anti-diagonal index and everything derived from it (LO[s], its residue mod P) is
-// wave-uniform and no per-cell division is needed.
-// ------------------------------------------------------------------------------------------------
-constexpr int PF = 3;            // anti-diagonals per prefetch group of k_recur (two groups ping-pong in registers)
-constexpr int REC_PAD = 2 * PF;  // spare anti-diagonals behind every matrix: the padded last groups of k_recur touch them
-constexpr int EMIS_T = 1024;
-__global__ __launch_bounds__(EMIS_T) void k_emis(BatchD b, int ndir) {
-    __shared__ double s_model[6 * NS];
-    const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
-    const JobD& J = b.jobs[job];
-    if (b.out[job].inert) return;
-    const double* gm = b.model + (size_t)J.ev * 6 * NS;
-    for (int k = threadIdx.x; k < 6 * NS; k += EMIS_T) s_model[k] = gm[k];
-    __syncthreads();
-    const int P = J.P, n0 = J.n0, C = J.C, W = J.W;
-    const int* __restrict__ lb = b.lb + J.lb_off;
-    const int* __restrict__ LO = b.lo + J.lo_off[dir];
-    const int* __restrict__ st = b.states + J.st_off;
-    const double* __restrict__ mean = b.mean + J.lev_off;
-    const double* __restrict__ stdv = b.stdv + J.lev_off;
-    const double* __restrict__ lsdv = b.logstdv + J.lev_off;
-    double* __restrict__ em = b.em + J.mat_off[dir];
-    unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
-    const int lane = threadIdx.x & 63;
-    const int nP = P >> 6;                                   // P is a multiple of 64
-    const int64_t nunits = (J.S + REC_PAD) * nP;             // the spare anti-diagonals get zero flags (k_recur reads them)
-    const int64_t nwaves = (int64_t)gridDim.x * (EMIS_T / 64);
-    const int64_t per = (nunits + nwaves - 1) / nwaves;
-    const int64_t u0 = min(nunits, ((int64_t)blockIdx.x * (EMIS_T / 64) + (threadIdx.x >> 6)) * per);
-    const int64_t u1 = min(nunits, u0 + per);
-    int s = __builtin_amdgcn_readfirstlane((int)(u0 / nP));
-    int c = __builtin_amdgcn_readfirstlane((int)(u0 - (int64_t)s * nP));
-    int lo = -1, lom = 0;
-    bool fresh = true;
-    for (int64_t u = u0; u < u1; u++) {
-        if (fresh) {   // a new anti-diagonal: its first in-band row and that row's slot
-            lo = s < J.S ? __builtin_amdgcn_readfirstlane(LO[s]) : -1;
-            lom = lo >= 0 ? lo % P : 0;
-            fresh = false;
-        }
-        const int slot = c * 64 + lane;
-        unsigned f = 0;
-        double e = 0.0;
-        if (lo >= 0) {
-            int d = slot - lom;
-            if (d < 0) d += P;
-            const int i = lo + d, j = s - i;
-            if (i <= n0 && j >= 1 && j <= C) {
-                int i0, i1;
-                band_of(lb, dir, j, C, n0, W, i0, i1);
-                if (i >= i0 && i <= i1) {
-                    const int state = st[dir == 0 ? j - 1 : C - j];
-                    if (state < 0) {
-                        // invalid 5-mer: the whole column is zero (cpp/Alignment.cpp:162-163).  Its step word is
-                        // final here; k_recur treats the cell like one outside the band (the same implicit zero for
-                        // its right-hand neighbours) and k_invfix stores the zero record afterwards.
-                        f = FLG_DEAD;
-                    } else {
-                        f = F_ACT;
-                        int p0, p1;
-                        if (j == 1) { p0 = 0; p1 = n0; f |= F_BLANK; }
-                        else band_of(lb, dir, j - 1, C, n0, W, p0, p1);
-                        if (i >= p0 && i <= p1) f |= F_VL;
-                        // (a diagonal neighbour in an invalid-5-mer column is a zero as well: leave F_RD clear)
-                        if (i > p0 && i <= p1) f |= F_VD | ((j == 1 || st[dir == 0 ? j - 2 : C - j + 1] < 0) ? 0u : F_RD);
-                        if (i == i0) f |= F_TOP;
-                        ModelRow m = {s_model[state], s_model[NS + state], s_model[2 * NS + state],
-                                      s_model[3 * NS + state], s_model[4 * NS + state], s_model[5 * NS + state]};
-                        // forward reads level i-1 but log_stdv[n0-i] (sic, cpp/Alignment.cpp:171-172); backward reads level n0-i
-                        const int tv = dir == 0 ? i - 1 : n0 - i;
-                        e = emission(m, mean[tv], stdv[tv], lsdv[n0 - i], b.log2pi, b.lik_offset);
-                    }
-                }
-            }
-        }
-        const int64_t cell = (int64_t)s * P + slot;
-        em[cell] = e;
-        flg[cell] = (unsigned short)f;
-        if (++c == nP) { c = 0; s++; fresh = true; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// recurrence pass: one workgroup (P lanes) per (job, direction).  Values only: the maximum over the
-// candidate moves equals the reference's ordered strict-'>' selection (cpp/Alignment.cpp:240-267)
-// whatever the tie order, so plain fmax is exact; the step codes are derived afterwards by k_steps.
-// A lane that has no in-band cell on an anti-diagonal holds zeros, which is exactly the reference's
-// "implicit zero" for neighbours outside the previous band (cpp/Alignment.cpp:201-225); a missing
-// upper neighbour (top row of a band) is -infinity for the stay / extend / insert moves.
+// k_fill: the whole of fillColumn / fillColumnBack (cpp/Alignment.cpp:111-274 / 280-444) for one alignment and
+// direction in one pass — emission log-densities, band flags, the recurrence, the back-pointer codes (forward) and
+// the per-column maxima — so a DP cell costs one 16-byte record (+ a 2-byte step word forward) of HBM traffic and
+// nothing is re-read.
+//
+// One workgroup of P lanes per (job, direction) sweeps the anti-diagonals s = i + j.  Lane `slot` holds the row
+// i == slot (mod P) that is inside [lo(s), lo(s) + P); its cell on anti-diagonal s is (i, s - i), so a lane walks
+// along one row, one column per step, until lo passes the row, then takes row i + P.  What a cell needs:
+//   (i, j-1)    the lane's own previous value (cm);
+//   (i-1, j)    what the lane one slot up published on the previous anti-diagonal  -> two LDS exchange buffers,
+//               written and read alternately, one LDS-only s_barrier per anti-diagonal;
+//   (i-1, j-1)  what that lane published two anti-diagonals ago = what this lane read one step earlier (dm).
+// A lane without a cell holds and publishes -infinity: read as the upper neighbour that is the top-row rule (no stay /
+// extend / insert into a band's first row), read as the left neighbour max(., 0) turns it into the reference's
+// "implicit zero" for neighbours outside the previous band (cpp/Alignment.cpp:201-225; real scores are >= 0).
+// Band flags come from lo / hi and the lane's own history instead of per-cell band lookups:
+//   in band        lo <= i <= hi
+//   top row        i == lo on an anti-diagonal where a new column starts (lo did not move)
+//   left valid     the lane's previous cell (same row, previous column) was in band, or this is column 1
+//   diag valid     the reference tests ROW i against the previous band (p0 < i <= p1): previous cell in band and
+//                  not that band's top row; the value is read as zero when the previous column is an invalid 5-mer
+// Values are computed with v_max chains (the maximum does not depend on the reference's tie order); the forward
+// step codes then follow from equality tests against the final value, which reproduce the ordered strict-'>'
+// selection of cpp/Alignment.cpp:240-267 (the first candidate, in the reference's order, that equals the maximum).
+//
+// Software pipeline (everything that does not depend on a neighbour runs ahead of the recurrence):
+//   head, 8 steps ahead     row / band flags of the lane on anti-diagonal s + 8 (ring of 8 entries);
+//   windows, 4-step groups  5-mer states of the lane's next four columns (one 16-byte load) and the level triple
+//                           of its row, fetched four steps before first use; a lane whose row changes inside a
+//                           window while it has a cell (only after an empty anti-diagonal) reloads directly;
+//   emission, 2 ahead       model row of the column's 5-mer from LDS (48 KB per event, transposed to 48-byte rows)
+//                           and the three IEEE divisions of cpp/AlignUtil.h:34-53;
+//   recurrence              exchange read, ~10 additions, max chain, codes, coalesced stores, exchange write.
+// Column maxima (MaxInfo per column) go through an LDS ring of ds_max and are flushed to memory as columns complete.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_shr1(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -286,251 +223,281 @@ __device__ __forceinline__ double wave_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
+enum : unsigned { H_INB = 1, H_TOP = 2, H_FIRST = 4, H_DEAD = 8, H_HAZ = 16 };
+constexpr int FB = 8;            // anti-diagonals per loop body = look-ahead of the head stage
+constexpr int CMAX_FLUSH = 64;   // anti-diagonals between two flushes of completed column maxima
 
 template <int DIR>
-struct RecurState {
-    double cm, cs;             // this lane's latest main / stay; -infinity while it has no cell
-    double pe = 0.0;           // backward pass: the emission this step's upper neighbour had one step earlier
-    unsigned hist = 0;         // wave-uniform: bit k set = the wave had a cell k anti-diagonals ago
-    int wa[3], ra[3];          // LDS byte offsets of this lane's slot / its upper neighbour's slot in the three buffers
+struct FillState {
+    double cm, cs;         // this lane's latest main / stay; -infinity while it has no cell
+    double dm, de;         // upper neighbour's main (and, backward, main + emission) as read one step earlier
+    double o1, o2;         // emission (+ lik_offset) of this lane's cell one / two anti-diagonals ahead
+    unsigned pf;           // head flags of the lane's previous anti-diagonal
+    int row;               // head: the lane's row on the newest anti-diagonal looked at
+    int wrow;              // head: that row at the start of the current 4-step window
+    int ri[FB];            // ring: row on anti-diagonals s .. s + 7
+    unsigned rf[FB];       // ring: flags
+    int stw[2][4];         // state windows (two groups in flight)
+    double lv[2][3];       // level windows {level mean, level stdv, log stdv}
 };
 
-// one anti-diagonal; PH = (anti-diagonal index) mod 3 selects the roles of the three exchange buffers.
-//
-// A lane without an in-band cell holds and publishes -infinity for main and stay.  Read as the upper neighbour
-// (row i-1 one step ago) that is what the stay / extend / insert moves of a band's top row need; read as the left
-// neighbour (the lane's own previous value) fmax(.., 0) turns it into the reference's "implicit zero" for
-// neighbours outside the previous band (cpp/Alignment.cpp:201-225) and leaves real scores, which are >= 0,
-// untouched.  This needs no flags because P exceeds the widest band footprint by two slots and the band edges
-// move at most one row per anti-diagonal (the band centres are bisection results, hence non-decreasing in the
-// column for any ref_index): a lane always idles for at least one step between two different rows.
-// Cells of invalid-5-mer columns are all zero; k_emis finishes them and marks them idle.
-// Two inputs keep a flag.  F_TOP: the stay matrix of a top row starts from -1e300 instead of 0.  F_RD: the
-// diagonal neighbour is taken only when this cell's own row lies inside the previous column's band — the
-// reference tests row i, not row i-1, against that band, so on the row just below the previous band's last row it
-// reads zero although cell (i-1, j-1) exists.
-// Neighbour values go through LDS for all lanes alike, in three rotating buffers: a cell reads what row i-1
-// published one step ago (upper neighbour) and two steps ago (diagonal neighbour) while this step's results go
-// to the third.  The backward recurrence adds the emission of the cell a move comes FROM (cpp/Alignment.cpp:
-// 284-330); those are plain reads of the emission matrix one slot up, one and two anti-diagonals back (`o` is that
-// stream in the backward pass, the cell's own emission in the forward pass), not part of the exchange.  A wave whose cells have all left the band runs three more all-idle steps, which put -infinity
-// into its slots of all three buffers, and then only takes part in the barrier until a cell comes back.
+struct __attribute__((aligned(4))) I4 { int x, y, z, w; };
+
+struct FillCtx {
+    const double* mean; const double* stdv; const double* lsd;
+    const int* st;
+    const int* LO; const int* HI;
+    double2* rec; unsigned short* flg;
+    const char* mdl;              // LDS: model rows [NS][6]
+    char* xch;                    // LDS: two exchange buffers of P records
+    unsigned long long* ring;     // LDS: column maxima, RCOLS entries
+    int ringmask;
+    int P, n0, C, slot;
+    int wa[2], ra[2];             // byte offsets of this lane's / its upper neighbour's record in the two buffers
+    double lsk, lst, lex, lin, off, log2pi;
+};
+
+template <int DIR>
+__device__ __forceinline__ double fill_emission(const FillCtx& c, int state, double x, double sd, double lsd) {
+    const char* row = c.mdl + (state < 0 ? 0 : state) * 48;
+    const double2 a = *(const double2*)row, bq = *(const double2*)(row + 16), cq = *(const double2*)(row + 32);
+    const ModelRow m = {a.x, a.y, bq.x, bq.y, cq.x, cq.y};
+    return emission(m, x, sd, lsd, c.log2pi, c.off);
+}
+
+// level triple of row i: forward reads level i-1 but log_stdv[n0-i] (sic, cpp/Alignment.cpp:171-172); backward level n0-i
+template <int DIR>
+__device__ __forceinline__ void fill_levels(const FillCtx& c, int i, double& x, double& sd, double& lsd) {
+    const int ic = clampi(i, 1, c.n0);
+    const int tv = DIR == 0 ? ic - 1 : c.n0 - ic;
+    x = c.mean[tv]; sd = c.stdv[tv]; lsd = c.lsd[c.n0 - ic];
+}
+// state of the lane's column on anti-diagonal t, row i (any t; out-of-range columns read the -1 padding)
+template <int DIR>
+__device__ __forceinline__ int fill_state_index(const FillCtx& c, int64_t t, int i) {
+    const int64_t j = t - i;
+    const int64_t idx = DIR == 0 ? j - 1 : (int64_t)c.C - j;
+    return (int)(idx < -3 ? -3 : (idx > c.C - 1 ? c.C - 1 : idx));   // windows read [idx, idx + 3]: inside the padding
+}
+
+// one anti-diagonal.  PH = position in the loop body (compile time): ring slot, exchange buffer, window set.
 template <int DIR, int PH>
-__device__ __forceinline__ void recur_step(RecurState<DIR>& r, const double o, const unsigned f, double2* __restrict__ dst,
-                                           char* __restrict__ xch, const double lsk, const double lst, const double lex,
-                                           const double lin) {
+__device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, const int64_t s, const int lo_h, const int hi_h,
+                                          const int lo_hp /* lo of anti-diagonal s + 7 */) {
     const double NINF = -__builtin_inf();
-    // scalar bookkeeping: number of lanes with a cell (s_bcnt1) -> one history bit per anti-diagonal
-    const unsigned nact = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(f & F_ACT));
-    r.hist = ((r.hist << 1) & 14u) | min(nact, 1u);
-    if (r.hist) {
-        constexpr int W0 = PH, R1 = (PH + 2) % 3, R2 = (PH + 1) % 3;   // written now / one step ago / two steps ago
-        // {main, stay} of row i-1 one step ago, main two steps ago
-        const double2 u = *(const double2*)(xch + r.ra[R1]);
-        const double dx = *(const double*)(xch + r.ra[R2]);
-        const bool rd = f & F_RD;
+    constexpr int G = PH >> 2, K = PH & 3;
+    const int i_s = r.ri[PH];
+    const unsigned f_s = r.rf[PH];
+    // ---- exchange read: what the lane one slot up published on the previous anti-diagonal
+    double um, us, ue = 0.0;
+    {
+        const char* p = c.xch + c.ra[(PH & 1) ^ 1];
+        const double2 u = *(const double2*)p;
+        um = u.x; us = u.y;
+        if (DIR) ue = *(const double*)(p + 16);
+    }
+    // ---- head: row and band flags of this lane on anti-diagonal s + 8
+    {
+        int i = r.row;
+        if (lo_h >= 0 && i < lo_h) {
+            i += c.P;
+            if (i < lo_h) {   // only after an empty stretch: the band resumes more than P rows further down
+                int d = (c.slot - lo_h) % c.P;
+                if (d < 0) d += c.P;
+                i = lo_h + d;
+            }
+        }
+        r.row = i;
+        if (((PH + 2) & 3) == 0) r.wrow = i;   // s + 8 starts a window (windows are the anti-diagonals 4w .. 4w+3; s0 == 2 mod 8)
+        const bool inb = lo_h >= 0 && i <= hi_h;
+        const bool newcol = lo_hp < 0 || lo_h == lo_hp;          // uniform: a column starts on this anti-diagonal
+        unsigned f = inb ? H_INB : 0u;
+        if (inb && i == lo_h && newcol) f |= H_TOP;
+        if (inb && s + FB - i == 1) f |= H_FIRST;
+        if (inb && i != r.wrow) f |= H_HAZ;                        // row changed inside the window and the lane has a cell
+        r.ri[PH] = i; r.rf[PH] = f;
+    }
+    // ---- windows: at a group start fetch the states / levels of anti-diagonals s + 6 .. s + 9
+    if (K == 0) {
+        const int wr = r.ri[(PH + 6) & 7];
+        const int64_t t0 = s + 6;
+        if (DIR == 0) {
+            const int a = fill_state_index<0>(c, t0, wr);          // ascending with the anti-diagonal
+            const I4 v = *(const I4*)(c.st + a);                   // 4-byte aligned 16-byte load
+            r.stw[G][0] = v.x; r.stw[G][1] = v.y; r.stw[G][2] = v.z; r.stw[G][3] = v.w;
+        } else {
+            const int a = fill_state_index<1>(c, t0 + 3, wr);      // descending: element 3 - k belongs to step t0 + k
+            const I4 v = *(const I4*)(c.st + a);
+            r.stw[G][0] = v.w; r.stw[G][1] = v.z; r.stw[G][2] = v.y; r.stw[G][3] = v.x;
+        }
+        fill_levels<DIR>(c, wr, r.lv[G][0], r.lv[G][1], r.lv[G][2]);
+    }
+    // ---- emission of anti-diagonal s + 2 (window fetched at the previous group start)
+    double o_new;
+    {
+        constexpr int M = (PH + 2) & 7;           // ring slot of s + 2
+        // s + 2 is element K of the window [4w, 4w+3] that the previous group start fetched (into set G ^ 1)
+        constexpr int SET = G ^ 1;
+        int state = r.stw[SET][K];
+        double x = r.lv[SET][0], sd = r.lv[SET][1], lsd = r.lv[SET][2];
+        if (r.rf[M] & H_HAZ) {                    // rare: direct loads for the lane's actual row
+            const int im = r.ri[M];
+            state = c.st[fill_state_index<DIR>(c, s + 2, im)];
+            fill_levels<DIR>(c, im, x, sd, lsd);
+        }
+        if (state < 0) r.rf[M] |= H_DEAD;
+        o_new = fill_emission<DIR>(c, state, x, sd, lsd);
+    }
+    // ---- recurrence on anti-diagonal s
+    {
+        const bool inb = f_s & H_INB, top = f_s & H_TOP, first = f_s & H_FIRST, dead = f_s & H_DEAD;
+        const bool pin = r.pf & H_INB;
+        const bool vd = first || (pin && !(r.pf & H_TOP));
+        const bool rd = vd && !first && !(r.pf & H_DEAD);
+        const double o = r.o1;
         double L;   // max(cm, 0) in one instruction (fmax() would first canonicalise its operand)
         asm("v_max_f64 %0, %1, 0" : "=v"(L) : "v"(r.cm));
-        const double D = rd ? dx : 0.0, po = rd ? r.pe : 0.0;
-        const double eo = o;
-        const double cSTAY = u.x + eo + lst;
-        const double cEXT = u.y + eo + lex;
-        const double cINS = u.x + lin;
-        const double cSKIP = L + lsk;
-        const double cMATCH = DIR == 0 ? D + o : D + po;
-        const double cIGN = D + lin;
-        double ns = (f & F_TOP) ? -BIG : 0.0;
-        ns = fmax(ns, cSTAY);
+        const double D = rd ? r.dm : 0.0;
+        const double cSTAY = DIR == 0 ? um + o + c.lst : ue + c.lst;       // backward: (main + emission) of the cell above
+        const double cEXT = DIR == 0 ? us + o + c.lex : us + c.lex;         // backward: `us` carries stay + emission
+        const double cINS = um + c.lin;
+        const double cSKIP = L + c.lsk;
+        const double cMATCH = DIR == 0 ? D + o : (rd ? r.de : 0.0);
+        const double cIGN = D + c.lin;
+        const double floor_s = top ? -BIG : 0.0;
+        double ns = fmax(floor_s, cSTAY);
         ns = fmax(ns, cEXT);
         double nm = fmax(0.0, cSKIP);
         nm = fmax(nm, cMATCH);
         nm = fmax(nm, cINS);
         nm = fmax(nm, cIGN);
         nm = fmax(nm, ns);
-        const bool act = f & F_ACT;
+        const bool act = inb && !dead;
         r.cm = act ? nm : NINF;
         r.cs = act ? ns : NINF;
-        *dst = make_double2(r.cm, r.cs);
-        *(double2*)(xch + r.wa[W0]) = make_double2(r.cm, r.cs);
+        // stored record: the cell, zeros for a cell of an invalid-5-mer column (cpp/Alignment.cpp:162-163)
+        const double2 recv = make_double2(act ? nm : (inb ? 0.0 : NINF), act ? ns : (inb ? 0.0 : NINF));
+        const int64_t cell = s * c.P + c.slot;
+        c.rec[cell] = recv;
+        if (DIR == 0) {
+            // back-pointer codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order
+            unsigned ss = cSTAY > floor_s ? M_STAY : 0u;
+            ss = cEXT > fmax(floor_s, cSTAY) ? M_EXTEND : ss;
+            unsigned sm = M_STAY;
+            sm = cIGN == nm ? M_IGNORE : sm;
+            sm = cINS == nm ? M_INSERT : sm;
+            sm = cMATCH == nm ? (vd ? M_MATCH : M_IMPL) : sm;
+            sm = cSKIP == nm ? M_SKIP : sm;
+            sm = nm > 0.0 ? sm : 0u;
+            // bits 14 / 15: main / stay score <= 0 (the backtrace stops there, cpp/Alignment.cpp:542)
+            const unsigned w = sm | (ss << 8) | (nm > 0.0 ? 0u : 0x4000u) | (ns > 0.0 ? 0u : 0x8000u);
+            c.flg[cell] = (unsigned short)(act ? w : FLG_DEAD);
+        }
+        // publish for the lane one slot down
+        char* q = c.xch + c.wa[PH & 1];
+        if (DIR == 0) {
+            *(double2*)q = make_double2(r.cm, r.cs);
+        } else {
+            *(double2*)q = make_double2(r.cm, r.cs + o);
+            *(double*)(q + 16) = r.cm + o;
+        }
+        // column maximum (scores are >= 0: their bit patterns order like unsigned integers)
+        if (act && nm > 0.0) atomicMax(&c.ring[(unsigned)(s - i_s) & c.ringmask], (unsigned long long)__double_as_longlong(nm));
+        r.dm = um; r.de = ue;
+        r.pf = f_s;
     }
-    if (DIR) r.pe = o;
+    r.o1 = r.o2; r.o2 = o_new;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int DIR>
-__device__ __forceinline__ void recur_body(const BatchD& b, const JobD& J, char* __restrict__ xch) {
+__device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* smem, const int rcols) {
     const int P = J.P, slot = threadIdx.x;
+    FillCtx c;
+    c.mean = J.mean; c.stdv = J.stdv; c.lsd = J.lsd; c.st = J.st;
+    c.LO = b.lo + J.lo_off[DIR]; c.HI = b.hi + J.lo_off[DIR];
+    c.rec = b.rec + J.mat_off[DIR]; c.flg = b.flg + J.mat_off[DIR];
+    c.P = P; c.n0 = J.n0; c.C = J.C; c.slot = slot;
+    c.lsk = J.lsk; c.lst = J.lst; c.lex = J.lex; c.lin = J.lin; c.off = J.lik_offset; c.log2pi = b.log2pi;
+    constexpr int RB = DIR ? 32 : 16;   // bytes per exchanged record: {main, stay} / {main, stay + em, main + em, -}
+    double* s_model = (double*)smem;
+    c.mdl = smem;
+    c.xch = smem + 6 * NS * sizeof(double);
+    c.ring = (unsigned long long*)(c.xch + 2 * P * 32);
+    c.ringmask = rcols - 1;
+    // the event's model, transposed to one 48-byte row per 5-mer
+    for (int k = slot; k < 6 * NS; k += P) s_model[(k & (NS - 1)) * 6 + (k >> 10)] = J.model[k];
+    for (int k = slot; k < rcols; k += P) c.ring[k] = 0ull;
     const int up_slot = slot == 0 ? P - 1 : slot - 1;
-    const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
-    // forward: the cell's own emission; backward: the emission of the cell one slot up on the previous anti-diagonal
-    const double* __restrict__ em = b.em + J.mat_off[DIR] + (DIR ? up_slot - P : slot);
-    const unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR] + slot;
-    double2* __restrict__ rec = b.rec + J.mat_off[DIR] + slot;
-    const int64_t S = J.S, SL = S - 1;
-    constexpr int RB = 16;   // bytes per exchanged record {main, stay}
     const double NINF = -__builtin_inf();
-    RecurState<DIR> r;
-    r.cm = NINF; r.cs = NINF;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        r.wa[k] = (k * P + slot) * RB;
-        r.ra[k] = (k * P + up_slot) * RB;
-        *(double2*)(xch + r.wa[k]) = make_double2(NINF, NINF);
+    for (int k = 0; k < 2; k++) {
+        c.wa[k] = (k * P + slot) * RB;
+        c.ra[k] = (k * P + up_slot) * RB;
+        *(double2*)(c.xch + c.wa[k]) = make_double2(NINF, NINF);
+        if (DIR) *(double*)(c.xch + c.wa[k] + 16) = NINF;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    FillState<DIR> r;
+    r.cm = NINF; r.cs = NINF; r.dm = NINF; r.de = NINF; r.o1 = 0.0; r.o2 = 0.0; r.pf = 0;
+    r.row = slot == 0 ? P : slot;   // rows start at 1: the smallest row of this slot's residue class
+    r.wrow = r.row;
+#pragma unroll
+    for (int k = 0; k < FB; k++) { r.ri[k] = r.row; r.rf[k] = 0; }
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.stw[g][k] = 0;
+        r.lv[g][0] = 0.0; r.lv[g][1] = 1.0; r.lv[g][2] = 0.0;
+    }
+    __syncthreads();
 
-    double eA[PF], eB[PF];
-    unsigned fA[PF], fB[PF];
-    // no tail handling: k_emis wrote zero flags on the REC_PAD spare anti-diagonals behind the matrix, which the
-    // padded last groups read (and, as idle lanes, store to).  PF is a multiple of 3, so the buffer roles are
-    // compile-time constants of the unrolled step index.
-#define PS_LOAD(E, F, s0)                                                   \
-    _Pragma("unroll") for (int u = 0; u < PF; u++) {                        \
-        const int64_t sc = min((int64_t)(s0) + u, SL + REC_PAD) * P;        \
-        E[u] = em[sc];                                                      \
-        F[u] = flg[sc];                                                     \
+    const int64_t S = J.S;
+    const int64_t s_first = 2 - FB;                      // the pipeline needs FB steps to fill; they fall into the front padding
+    int flushed = 1;                                     // columns below this have their maximum in memory
+    double* gcmax = b.cmax + J.col_off[DIR];
+    int lo_hp = -1;                                      // lo of the anti-diagonal before the head's
+    for (int64_t s0 = s_first; s0 < S; s0 += FB) {
+        // lo / hi of the anti-diagonals the head stages of this body look at (uniform: scalar loads)
+        int lov[FB], hiv[FB];
+#pragma unroll
+        for (int k = 0; k < FB; k++) { lov[k] = c.LO[s0 + FB + k]; hiv[k] = c.HI[s0 + FB + k]; }
+        fill_step<DIR, 0>(r, c, s0 + 0, lov[0], hiv[0], lo_hp);
+        fill_step<DIR, 1>(r, c, s0 + 1, lov[1], hiv[1], lov[0]);
+        fill_step<DIR, 2>(r, c, s0 + 2, lov[2], hiv[2], lov[1]);
+        fill_step<DIR, 3>(r, c, s0 + 3, lov[3], hiv[3], lov[2]);
+        fill_step<DIR, 4>(r, c, s0 + 4, lov[4], hiv[4], lov[3]);
+        fill_step<DIR, 5>(r, c, s0 + 5, lov[5], hiv[5], lov[4]);
+        fill_step<DIR, 6>(r, c, s0 + 6, lov[6], hiv[6], lov[5]);
+        fill_step<DIR, 7>(r, c, s0 + 7, lov[7], hiv[7], lov[6]);
+        lo_hp = lov[7];
+        // flush the maxima of completed columns: every column left of the oldest one still present on the next anti-diagonal
+        if ((((s0 - s_first) / FB) & (CMAX_FLUSH / FB - 1)) == CMAX_FLUSH / FB - 1) {
+            const int64_t sn = s0 + FB;
+            const int lo_n = c.LO[sn], hi_n = c.HI[sn];
+            if (lo_n >= 0) {
+                const int jdone = (int)(sn - hi_n);      // oldest column still present
+                for (int col = flushed + slot; col < jdone; col += P) {
+                    const unsigned long long v = c.ring[col & c.ringmask];
+                    c.ring[col & c.ringmask] = 0ull;
+                    gcmax[col] = __longlong_as_double((long long)v);
+                }
+                flushed = max(flushed, jdone);
+            }
+        }
     }
-#define PS_STEP(E, F, s0, u) recur_step<DIR, (u) % 3>(r, E[u], F[u], rec + ((int64_t)(s0) + (u)) * P, xch, lsk, lst, lex, lin);
-#define PS_RUN(E, F, s0) PS_STEP(E, F, s0, 0) PS_STEP(E, F, s0, 1) PS_STEP(E, F, s0, 2)
-    static_assert(PF == 3, "PS_RUN is written out for three steps per group");
-    PS_LOAD(eA, fA, 2)
-    for (int64_t s0 = 2; s0 < S; s0 += 2 * PF) {   // every wave runs the same padded trip count
-        PS_LOAD(eB, fB, s0 + PF)
-        PS_RUN(eA, fA, s0)
-        PS_LOAD(eA, fA, s0 + 2 * PF)
-        PS_RUN(eB, fB, s0 + PF)
-    }
-#undef PS_LOAD
-#undef PS_STEP
-#undef PS_RUN
+    __syncthreads();
+    for (int col = flushed + slot; col <= J.C; col += P) gcmax[col] = __longlong_as_double((long long)c.ring[col & c.ringmask]);
 }
 
-// zero records of the invalid-5-mer cells (k_recur leaves -infinity in idle slots); launched only for batches whose
-// sequences contain an invalid 5-mer.  grid (nblk, njobs*ndir), block 256
-__global__ __launch_bounds__(256) void k_invfix(BatchD b, int ndir) {
-    const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
-    const JobD& J = b.jobs[job];
-    if (b.out[job].inert) return;
-    const unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
-    double2* __restrict__ rec = b.rec + J.mat_off[dir];
-    const int64_t ncell = J.S * J.P;
-    for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < ncell; cell += (int64_t)gridDim.x * 256)
-        if (flg[cell] == FLG_DEAD) rec[cell] = make_double2(0.0, 0.0);
-}
-
-__global__ __launch_bounds__(1024) void k_recur(BatchD b, int ndir) {
-    extern __shared__ double2 xch2[];   // three exchange buffers of P {main, stay} records
-    char* xch = (char*)xch2;
+// MAXT = 512 lets the compiler keep the whole pipeline in registers (LDS already limits a CU to two such workgroups);
+// bands wider than 512 slots take the 1024-thread build
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void k_fill(BatchD b, int ndir, int rcols) {
+    extern __shared__ double2 fill_smem[];
     const int jd = blockIdx.x, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
-    if (b.out[job].inert) return;
-    if (dir == 0) recur_body<0>(b, J, xch); else recur_body<1>(b, J, xch);
-}
-
-// ------------------------------------------------------------------------------------------------
-// step / statistics pass, chip-wide and coalesced in the skewed layout:
-//   * forward direction: re-derive each cell's back-pointer codes with the reference's ordered
-//     strict-'>' selection from the stored neighbour values (cpp/Alignment.cpp:196-267)
-//   * both directions: per-column maximum of the main matrix (-> MaxInfo per column), aggregated in
-//     LDS per block of SB anti-diagonals, then one global atomic max per touched column
-// grid (ceil(maxS / SB), njobs*ndir), block 256
-// ------------------------------------------------------------------------------------------------
-constexpr int SB = 32;
-constexpr int SCOLS = 2048;
-
-__global__ __launch_bounds__(256) void k_steps(BatchD b, int ndir) {
-    __shared__ unsigned long long s_cmax[SCOLS];
-    __shared__ int s_jbase, s_ok;
-    const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
-    const JobD& J = b.jobs[job];
-    if (b.out[job].inert) return;
-    const int64_t s0 = (int64_t)blockIdx.x * SB;
-    if (s0 >= J.S) return;
-    const int nst = (int)min((int64_t)SB, J.S - s0);
-    const int P = J.P;
-    const int* __restrict__ LO = b.lo + J.lo_off[dir];
-    if (threadIdx.x == 0) {
-        int jmin = 0x7fffffff, jmax = -1;
-        for (int k = 0; k < nst; k++) {
-            const int lo = LO[s0 + k];
-            if (lo < 0) continue;
-            const int s = (int)(s0 + k);
-            jmax = max(jmax, s - lo);
-            jmin = min(jmin, s - lo - P + 1);
-        }
-        s_jbase = jmin;
-        s_ok = (jmax >= 0 && jmax - jmin + 1 <= SCOLS) ? 1 : (jmax < 0 ? -1 : 0);
-    }
-    for (int k = threadIdx.x; k < SCOLS; k += 256) s_cmax[k] = 0ull;
-    __syncthreads();
-    if (s_ok < 0) return;  // nothing in band on these anti-diagonals
-    const bool use_lds = s_ok == 1;
-    const int jbase = s_jbase;
-    const double2* __restrict__ rec = b.rec + J.mat_off[dir];
-    const double* __restrict__ em = b.em + J.mat_off[dir];
-    unsigned short* __restrict__ flg = b.flg + J.mat_off[dir];
-    unsigned long long* gcmax = (unsigned long long*)(b.cmax + J.col_off[dir]);
-    const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
-    // work unit = one wave-wide run of 64 slots of one anti-diagonal (k, c): k and LO are wave-uniform
-    const int nP = P >> 6, lane = threadIdx.x & 63;
-    int k = 0, c = threadIdx.x >> 6;
-    while (c >= nP) { c -= nP; k++; }
-    for (; k < nst; ) {
-        const int64_t s = s0 + k;
-        const int slot = c * 64 + lane;
-        const int64_t cell = s * P + slot;
-        const int lo = __builtin_amdgcn_readfirstlane(LO[s]);
-        const unsigned f = lo >= 0 ? flg[cell] : 0u;
-        c += 4;
-        while (c >= nP) { c -= nP; k++; }
-        if (!(f & F_ACT)) continue;
-        int d = slot - lo % P;
-        if (d < 0) d += P;
-        const int i = lo + d;
-        const int j = (int)s - i;
-        const double2 v = rec[cell];
-        if (v.x > 0.0) {
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(v.x);
-            if (use_lds) atomicMax(&s_cmax[j - jbase], bits); else atomicMax(&gcmax[j], bits);
-        }
-        if (dir == 0) {
-            unsigned sm = 0, ss = 0;
-            {
-                const int sm1 = slot == 0 ? P - 1 : slot - 1;
-                const double o = em[cell];
-                double L = 0.0, D = 0.0, um = 0.0, us = 0.0;
-                const bool blank = f & F_BLANK, vl = f & F_VL, vd = f & F_VD, top = f & F_TOP;
-                if (vl && !blank) L = rec[cell - P].x;
-                if (vd && !blank) D = rec[(s - 2) * P + sm1].x;
-                if (!top) { const double2 u = rec[(s - 1) * P + sm1]; um = u.x; us = u.y; }
-                const double cSKIP = vl ? L + lsk : lsk;
-                const unsigned kSKIP = vl ? M_SKIP : M_IMPL;
-                const double cMATCH = vd ? D + o : o;
-                const unsigned kMATCH = vd ? M_MATCH : M_IMPL;
-                const double cIGN = vd ? D + lin : 0.0;
-                double cSTAY = -BIG, cEXT = -BIG, cINS = 0.0, ns = 0.0, nm = 0.0;
-                if (top) ns = -BIG;
-                else { cSTAY = um + o + lst; cINS = um + lin; cEXT = us + o + lex; }
-                if (cSTAY > ns) { ns = cSTAY; ss = M_STAY; }
-                if (cEXT > ns) { ns = cEXT; ss = M_EXTEND; }
-                if (cSKIP > nm) { nm = cSKIP; sm = kSKIP; }
-                if (cMATCH > nm) { nm = cMATCH; sm = kMATCH; }
-                if (cINS > nm) { nm = cINS; sm = M_INSERT; }
-                if (cIGN > nm) { nm = cIGN; sm = M_IGNORE; }
-                if (ns > nm) { nm = ns; sm = M_STAY; }
-            }
-            // bits 14 / 15: main / stay score <= 0 (the backtrace stops there, cpp/Alignment.cpp:542) so that the
-            // walker needs nothing but this word
-            flg[cell] = (unsigned short)(sm | (ss << 8) | (v.x <= 0.0 ? 0x4000u : 0u) | (v.y <= 0.0 ? 0x8000u : 0u));
-        }
-    }
-    if (use_lds) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < SCOLS; k += 256) {
-            const unsigned long long v = s_cmax[k];
-            if (v) atomicMax(&gcmax[jbase + k], v);
-        }
-    }
+    if (J.out->inert) return;
+    if (dir == 0) fill_body<0>(b, J, (char*)fill_smem, rcols); else fill_body<1>(b, J, (char*)fill_smem, rcols);
 }
 
 // prefix max over columns + (fwd) the first cell achieving the global max ; grid njobs*ndir, block 64
@@ -571,7 +538,7 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
             for (int off = 32; off; off >>= 1) bi = min(bi, __shfl_xor(bi, off));
         }
         if (lane == 0) {
-            JobOut* O = b.out + job;
+            JobOut* O = J.out;
             O->best = best;
             if (best > 0.0) { O->bj = bj; O->bi = bi; }
             else { O->bj = 0; O->bi = 0; }
@@ -606,7 +573,7 @@ __device__ __forceinline__ void bt_load(unsigned short (*__restrict__ dst)[BT + 
     for (int q = 0; q < NQ; q++) { const int idx = t + NT * q; if (idx < BT * BT) dst[idx / BT][idx % BT] = tmp[q]; }
 }
 
-// The walker navigates on the 16-bit step words alone (codes + "score <= 0" bits written by k_steps), so a
+// The walker navigates on the 16-bit step words alone (codes + "score <= 0" bits written by k_fill), so a
 // tile is 64 x 64 cells = 8 KB of LDS.  Wave 0 walks the current tile while waves 1-3 fetch the tile the path
 // is expected to enter next (same diagonal, BTM cells of overlap to absorb drift) into the other LDS buffer; when
 // the walk leaves the current tile inside the prefetched one no load is waited for.  For every recorded level
@@ -614,8 +581,8 @@ __device__ __forceinline__ void bt_load(unsigned short (*__restrict__ dst)[BT + 
 // (column << 1 | matrix); k_fill_like then replaces those by the stored scores in parallel.
 __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
     const JobD& J = b.jobs[blockIdx.x];
-    if (b.out[blockIdx.x].inert) return;  // stripe_width == 0: the event is left untouched
-    const JobOut O = b.out[blockIdx.x];
+    const JobOut O = *J.out;
+    if (O.inert) return;  // stripe_width == 0: the event is left untouched
     const int tid = threadIdx.x, P = J.P, n0 = J.n0;
     double* __restrict__ ra = J.ra;
     long long* __restrict__ rlw = (long long*)J.rl;
@@ -694,7 +661,7 @@ __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
 // ref_like[i-1] = score of the cell level i was recorded from (cpp/Alignment.cpp:610-618); grid (ceil(maxn/256), njobs)
 __global__ __launch_bounds__(256) void k_fill_like(BatchD b) {
     const JobD& J = b.jobs[blockIdx.y];
-    if (b.out[blockIdx.y].inert) return;
+    if (J.out->inert) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= J.n0) return;
     const long long w = ((const long long*)J.rl)[t];
@@ -737,7 +704,7 @@ __device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, 
 // old score for each distinct r0 = max(start - 3, 1) ; grid (nr0, njobs), block 64
 __global__ __launch_bounds__(64) void k_old(BatchD b, ScoreArgs a) {
     const JobD& J = b.jobs[blockIdx.y];
-    if (b.out[blockIdx.y].inert) return;
+    if (J.out->inert) return;
     const int r0 = a.r0[blockIdx.x];
     const double v = colmax_pair(b, J, r0, J.C - r0 + 1, threadIdx.x, 64);
     if (threadIdx.x == 0) a.old[(size_t)blockIdx.y * a.nr0 + blockIdx.x] = v;
@@ -759,7 +726,7 @@ __global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int*
     const bool have = it < nitems;
     const int m = have ? items[it] : 0;
     const int n0 = J.n0, C = J.C, P = J.P, WS = a.ws;
-    const bool live = have && !b.out[job].inert && !a.m_skip[m];
+    const bool live = have && !J.out->inert && !a.m_skip[m];
     if (__ballot(live) == 0ull) {
         if (have && c == 0) a.delta[(size_t)job * a.nitems_per_job + m] = 0.0;
         return;
@@ -772,13 +739,13 @@ __global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int*
     if ((unsigned)backind >= (unsigned)(C + 1)) backind = C;
     const int* __restrict__ lbf = b.lb + J.lb_off;    // tables the fills were made with
     const int* __restrict__ lbn = b.lb + J.lbn_off;   // after the backtrace: centres of the new columns
-    const double* __restrict__ mean = b.mean + J.lev_off;
-    const double* __restrict__ stdv = b.stdv + J.lev_off;
-    const double* __restrict__ lsdv = b.logstdv + J.lev_off;
+    const double* __restrict__ mean = J.mean;
+    const double* __restrict__ stdv = J.stdv;
+    const double* __restrict__ lsdv = J.lsd;
     const double2* __restrict__ rf = b.rec + J.mat_off[0];
     const double2* __restrict__ rb = b.rec + J.mat_off[1];
-    const double* gm = b.model + (size_t)J.ev * 6 * NS;
-    const double lsk = b.trans[J.ev * 4 + 0], lst = b.trans[J.ev * 4 + 1], lex = b.trans[J.ev * 4 + 2], lin = b.trans[J.ev * 4 + 3];
+    const double* gm = J.model;
+    const double lsk = J.lsk, lst = J.lst, lex = J.lex, lin = J.lin;
 
     // band of the back column the target is combined with
     int bb0 = 0, bb1 = n0;
@@ -832,7 +799,7 @@ __global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int*
             if (mine && i >= i0 && i <= i1) {
                 double nm = 0.0, ns = 0.0;
                 if (state >= 0) {
-                    const double o = emission(mr, mean[i - 1], stdv[i - 1], lsdv[n0 - i], b.log2pi, b.lik_offset);
+                    const double o = emission(mr, mean[i - 1], stdv[i - 1], lsdv[n0 - i], b.log2pi, J.lik_offset);
                     const bool vl = i >= p0 && i <= p1, vd = i > p0 && i <= p1;
                     const double cSKIP = vl ? L + lsk : lsk;
                     const double cMATCH = vd ? D + o : o;
@@ -902,9 +869,11 @@ __global__ void k_reduce(ScoreArgs a, int njobs) {
 // latch the reference's "stripe_width == 0" decision (cpp/Alignment.cpp:51-59) for this API call
 __global__ void k_begin(BatchD b) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) *b.maxw = 0;
     if (j >= b.njobs) return;
-    b.out[j].inert = (b.jobs[j].force_inert || !b.out[j].has_index) ? 1 : 0;
-    b.out[j].best = 0.0; b.out[j].bi = 0; b.out[j].bj = 0; b.out[j].maxw = 0;
+    JobOut* O = b.jobs[j].out;
+    O->inert = (b.jobs[j].force_inert || !O->has_index) ? 1 : 0;
+    O->best = 0.0; O->bi = 0; O->bj = 0;
 }
 
 // =================================================================================================
@@ -929,29 +898,30 @@ int launch_lb(Runtime* rt, const BatchD& b, int which, int maxlbn) {
 
 int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS) {
     if (!b.njobs) return PS_OK;
-    hipLaunchKernelGGL(k_lo, dim3((unsigned)((maxS + 255) / 256), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
+    hipLaunchKernelGGL(k_lo, dim3((unsigned)((maxS + LO_PAD + 255) / 256), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
 
-int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols, bool has_invalid) {
+// LDS of one k_fill workgroup: the event's model (48 KB), two exchange buffers, the column-maxima ring
+static int fill_ring_cols(int P) { return P + 128 <= 1024 ? 1024 : (P + 128 <= 2048 ? 2048 : 4096); }
+static size_t fill_lds_bytes(int P) { return 6 * NS * sizeof(double) + (size_t)2 * P * 32 + (size_t)fill_ring_cols(P) * 8; }
+
+int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols) {
     if (!b.njobs) return PS_OK;
-    // ~2048 workgroups of 16 waves over the chip, at least ~64 wave-units per wave
-    int nblk = (int)std::min<int64_t>((maxS * (P / 64) + 16 * 64 - 1) / (16 * 64), std::max(4, 2048 / (b.njobs * ndir)));
-    nblk = std::max(nblk, 1);
-    hipLaunchKernelGGL(k_emis, dim3(nblk, b.njobs * ndir), dim3(EMIS_T), 0, rt->stream, b, ndir);
-    PS_LAUNCH_CHECK();
-    prof_begin(rt);
-    hipLaunchKernelGGL(k_recur, dim3(b.njobs * ndir), dim3(P), 3 * P * sizeof(double2), rt->stream, b, ndir);
-    PS_LAUNCH_CHECK();
-    prof_end(rt, "fill", 0.0);
-    if (has_invalid) {
-        hipLaunchKernelGGL(k_invfix, dim3(std::max(1, 1024 / (b.njobs * ndir)), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
-        PS_LAUNCH_CHECK();
+    (void)maxS;
+    static bool attr_set = false;   // more than the default 64 KB of dynamic LDS needs the attribute (idempotent; racing threads set the same value)
+    if (!attr_set) {
+        PS_HIP(hipFuncSetAttribute((const void*)k_fill<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PS_HIP(hipFuncSetAttribute((const void*)k_fill<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
     }
     PS_HIP(hipMemsetAsync(b.cmax, 0, ncols * sizeof(double), rt->stream));
-    hipLaunchKernelGGL(k_steps, dim3((unsigned)((maxS + SB - 1) / SB), b.njobs * ndir), dim3(256), 0, rt->stream, b, ndir);
+    prof_begin(rt);
+    if (P <= 512) hipLaunchKernelGGL(k_fill<512>, dim3(b.njobs * ndir), dim3(P), fill_lds_bytes(P), rt->stream, b, ndir, fill_ring_cols(P));
+    else hipLaunchKernelGGL(k_fill<1024>, dim3(b.njobs * ndir), dim3(P), fill_lds_bytes(P), rt->stream, b, ndir, fill_ring_cols(P));
     PS_LAUNCH_CHECK();
+    prof_end(rt, "fill", 0.0);
     hipLaunchKernelGGL(k_prefix, dim3(b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
     PS_LAUNCH_CHECK();
     return PS_OK;

@@ -27,7 +27,6 @@ namespace ps {
 
 constexpr int SWB = 8;    // rows per pipeline step
 constexpr int SWW = 8;    // waves per workgroup: two per SIMD keeps one pair's strips issue-balanced over several CUs
-constexpr bool getenv_nocs = false;
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp_max(int v) {   // lanes without a source keep their own value
