@@ -218,6 +218,7 @@ std::string apply_edit(const std::string& b, const Mut& m) {
 int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int lb_extra) {
     ndir = ndir_;
     P = 0; Pmax = 64;
+    d.fastdiv = 1;
     jobs.clear();
     maxS = 0; maxC = 0; maxn = 0; maxlbn = 0;
     constexpr int ST_PAD = 8;   // ints of -1 around every state list: k_fill fetches four states per 16-byte load
@@ -231,13 +232,16 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
         const int W = a->par.realign_width;
         if (W < 0) return fail(PS_ERR_BAD_ARG, "realign_width < 0");
         // widest possible footprint 2W + 1, plus the idle slots k_fill wants between two rows of a lane
-        const int pm = std::max(64, ((2 * W + 6 + 63) / 64) * 64);
-        if (pm > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 509: band wider than one workgroup");
+        const int pm = std::max(64, ((2 * W + 10 + 63) / 64) * 64);
+        if (pm > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 507: band wider than one workgroup");
         Pmax = std::max(Pmax, pm);
         JobD j;
         memset(&j, 0, sizeof(j));
         j.mean = a->d_mean + a->off[s.ev]; j.stdv = a->d_stdv + a->off[s.ev]; j.lsd = a->d_lsd + a->off[s.ev];
         j.model = a->d_model + (size_t)s.ev * 6 * NS;
+        j.model8 = a->d_model8 + (size_t)s.ev * 8 * NS;
+        j.lev[0] = a->d_lev[0] + 4 * a->off[s.ev]; j.lev[1] = a->d_lev[1] + 4 * a->off[s.ev];
+        if (!a->fastdiv) d.fastdiv = 0;
         j.lsk = a->h_trans[s.ev * 4 + 0]; j.lst = a->h_trans[s.ev * 4 + 1]; j.lex = a->h_trans[s.ev * 4 + 2]; j.lin = a->h_trans[s.ev * 4 + 3];
         j.lik_offset = a->par.lik_offset;
         j.n0 = a->n[s.ev]; j.C = (int)s.states->size(); j.W = W; j.P = 0;
@@ -354,9 +358,37 @@ int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_event
     }
     h_model = mdl;
     h_trans = tr;
+    // k_fill's tables: model rows with the reciprocals of the two model divisors, level records per direction with the
+    // reciprocal of the level stdv (correctly rounded: host IEEE division)
+    std::vector<double> mdl8((size_t)E * 8 * NS), lev((size_t)2 * 4 * std::max<int64_t>(ntot, 1));
+    auto sane = [](double v) { return std::isfinite(v) && v > 1e-100 && v < 1e100; };
+    fastdiv = true;
+    for (int e = 0; e < E; e++) {
+        const double* d6 = mdl.data() + (size_t)e * 6 * NS;
+        double* d8 = mdl8.data() + (size_t)e * 8 * NS;
+        for (int k = 0; k < NS; k++) {
+            const double lm = d6[k], ls = d6[NS + k], sm = d6[3 * NS + k], lam = d6[4 * NS + k];
+            double* r8 = d8 + (size_t)k * 8;
+            r8[0] = lm; r8[1] = 1.0 / ls; r8[2] = ls; r8[3] = d6[2 * NS + k];
+            r8[4] = sm; r8[5] = 1.0 / sm; r8[6] = lam; r8[7] = d6[5 * NS + k];
+            if (!sane(ls) || !sane(sm) || !std::isfinite(lm) || !std::isfinite(lam) || std::fabs(lm) > 1e100 || std::fabs(lam) > 1e100) fastdiv = false;
+        }
+        const int64_t o = off[e];
+        const int ne = n[e];
+        for (int i = 1; i <= ne; i++) {
+            double* f = lev.data() + 4 * (o + i - 1);
+            double* bk = lev.data() + 4 * (ntot + o + i - 1);
+            const double l3 = 3 * lsd[o + ne - i];
+            f[0] = h_mean[o + i - 1]; f[1] = h_stdv[o + i - 1]; f[2] = l3; f[3] = 1.0 / h_stdv[o + i - 1];
+            bk[0] = h_mean[o + ne - i]; bk[1] = h_stdv[o + ne - i]; bk[2] = l3; bk[3] = 1.0 / h_stdv[o + ne - i];
+        }
+    }
+    for (int64_t t = 0; t < ntot; t++)
+        if (!sane(h_stdv[t]) || !std::isfinite(h_mean[t]) || std::fabs(h_mean[t]) > 1e100) fastdiv = false;
+    if (getenv("PORESEQ_EXACT_DIV")) fastdiv = false;   // tests: run the IEEE-division build of k_fill
     // one slab: mean, stdv, lsd, ra, rl, ri [ntot each] | model | trans | out
     const size_t nlev = (size_t)std::max<int64_t>(ntot, 1);
-    const size_t bytes = 6 * nlev * sizeof(double) + (mdl.size() + tr.size() + 2) * sizeof(double) +
+    const size_t bytes = (6 + 8) * nlev * sizeof(double) + (mdl.size() + mdl8.size() + tr.size() + 2) * sizeof(double) + 256 +
                          (size_t)std::max(E, 1) * sizeof(JobOut) + 64 * 16;
     PS_HIP(hipMalloc(&slab, bytes));
     char* p = (char*)slab;
@@ -365,16 +397,21 @@ int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_event
     d_ra = (double*)carve(nlev * 8); d_rl = (double*)carve(nlev * 8); d_ri = (double*)carve(nlev * 8);
     d_model = (double*)carve(std::max<size_t>(mdl.size(), 1) * 8); d_trans = (double*)carve(std::max<size_t>(tr.size(), 1) * 8);
     d_out = (JobOut*)carve((size_t)std::max(E, 1) * sizeof(JobOut));
+    d_model8 = (double*)carve(std::max<size_t>(mdl8.size(), 1) * 8);
+    d_lev[0] = (double*)carve(4 * nlev * 8); d_lev[1] = (double*)carve(4 * nlev * 8);
     if (ntot) {
         PS_HIP(hipMemcpyAsync(d_mean, h_mean.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
         PS_HIP(hipMemcpyAsync(d_stdv, h_stdv.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
         PS_HIP(hipMemcpyAsync(d_lsd, lsd.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
         PS_HIP(hipMemcpyAsync(d_ra, h_ra.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
         PS_HIP(hipMemcpyAsync(d_rl, h_rl.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
+        PS_HIP(hipMemcpyAsync(d_lev[0], lev.data(), 4 * ntot * 8, hipMemcpyHostToDevice, rt->stream));
+        PS_HIP(hipMemcpyAsync(d_lev[1], lev.data() + 4 * ntot, 4 * ntot * 8, hipMemcpyHostToDevice, rt->stream));
     }
     if (E) {
         PS_HIP(hipMemcpyAsync(d_model, mdl.data(), mdl.size() * 8, hipMemcpyHostToDevice, rt->stream));
         PS_HIP(hipMemcpyAsync(d_trans, tr.data(), tr.size() * 8, hipMemcpyHostToDevice, rt->stream));
+        PS_HIP(hipMemcpyAsync(d_model8, mdl8.data(), mdl8.size() * 8, hipMemcpyHostToDevice, rt->stream));
     }
     PS_HIP(hipMemsetAsync(d_out, 0, (size_t)std::max(E, 1) * sizeof(JobOut), rt->stream));
     PS_HIP(hipStreamSynchronize(rt->stream));
@@ -418,9 +455,9 @@ int realign(Runtime* rt, Batch& b) {
     int* w = nullptr;
     PS_TRY(rt->down(&w, b.d.maxw, (size_t)1));
     PS_HIP(hipStreamSynchronize(rt->stream));
-    // five slots more than the widest footprint: a lane idles at least four anti-diagonals between two rows, so a
-    // four-step prefetch window of k_fill never spans two rows of a lane that has a cell
-    PS_TRY(b.place(rt, std::max(*w, 1) + 5));
+    // nine slots more than the widest footprint: a lane idles at least nine anti-diagonals between two rows, so a prefetch
+    // window of k_fill (fetched six steps ahead, four steps long) never spans two rows of a lane that has a cell
+    PS_TRY(b.place(rt, std::max(*w, 1) + 9));
     if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes();
     PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P, b.ncols));
     PS_TRY(launch_backtrace(rt, b.d, b.maxn));

@@ -54,6 +54,8 @@ struct Align {
     void* slab = nullptr;
     double *d_mean = nullptr, *d_stdv = nullptr, *d_lsd = nullptr, *d_ra = nullptr, *d_rl = nullptr, *d_ri = nullptr;
     double *d_model = nullptr, *d_trans = nullptr;
+    double *d_model8 = nullptr, *d_lev[2] = {nullptr, nullptr};   // k_fill's tables (ps_internal.h, JobD)
+    bool fastdiv = true;                                          // tabulated reciprocals are usable (all divisors sane)
     JobOut* d_out = nullptr;
     std::map<std::string, std::vector<double>> seqlikes;  // cpp/AlignData.h:34
 

@@ -117,6 +117,9 @@ struct JobD {
     const double* stdv;
     const double* lsd;    // log(stdv), host libm
     const double* model;  // derived model of the event, [6][1024]: lev_mean, lev_stdv, log_lev, sd_mean, sd_lambda, log_lambda
+    const double* model8; // the same per 5-mer, [1024][8]: mean, 1/stdv, stdv, log stdv, sd mean, 1/sd mean, lambda, log lambda (k_fill)
+    const double* lev[2]; // level records per direction, [n0][4]: forward row i -> {mean[i-1], stdv[i-1], 3 lsd[n0-i], 1/stdv[i-1]},
+                          //                                      backward row i -> the same of level n0-i (cpp/Alignment.cpp:171-172, 345-349)
     const int* st;        // 5-mer states of the job's sequence [C] (4 ints of -1 padding on either side)
     double lsk, lst, lex, lin;   // log transition probabilities: skip, stay, extend, insert
     double lik_offset;
@@ -126,6 +129,7 @@ struct JobD {
     int force_inert; // realign_width == 0: every Alignment is a no-op (cpp/Alignment.cpp:85-86)
     int P;           // slots per anti-diagonal (multiple of 64, >= widest footprint + 5)
     int lbn;         // entries in each lb table (C + 2 + extra)
+    int pad0, pad1;
     int64_t lb_off;      // lb table the fills were made with          (int32[lbn])
     int64_t lbn_off;     // lb table after the latest backtrace        (int32[lbn])
     int64_t mat_off[2];  // record offset of anti-diagonal 0 of the forward / backward matrix
@@ -150,7 +154,7 @@ struct JobOut {
 
 constexpr int MAT_FRONT = 8;   // spare anti-diagonals in front of every matrix (the fill pipeline starts 8 steps early)
 constexpr int MAT_BACK = 16;   // and behind it (the last loop body runs past S)
-constexpr int LO_PAD = 32;     // LO / HI entries behind S, all -1
+constexpr int LO_PAD = 160;    // LO / HI entries behind S, all -1 (k_fill prefetches them in chunks of 64)
 
 // device pointers of the pools a batch of jobs lives in (filled by Batch::build / place)
 struct BatchD {
@@ -164,6 +168,7 @@ struct BatchD {
     double* cmax;                         // per column max of main
     double* pm;                           // prefix max over columns (MaxInfo.score per column)
     int* maxw;                            // widest band footprint of any job of the batch on one anti-diagonal (sizes P)
+    int fastdiv;                          // every AlignData of the batch allows k_fill's tabulated reciprocals
     double log2pi;
 };
 

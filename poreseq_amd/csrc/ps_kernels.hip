@@ -206,14 +206,26 @@ __global__ __launch_bounds__(256) void k_lo(BatchD b, int ndir) {
 // step codes then follow from equality tests against the final value, which reproduce the ordered strict-'>'
 // selection of cpp/Alignment.cpp:240-267 (the first candidate, in the reference's order, that equals the maximum).
 //
+// Divisions.  The three divisors of an emission (cpp/AlignUtil.h:34-53) are table values: the 5-mer's level stdv and sd
+// mean, and the level's own stdv.  Their correctly rounded reciprocals y = RN(1/b) are tabulated (host IEEE division) and
+// a/b is formed as  q0 = a*y; r = fma(-b,q0,a); q1 = fma(r,y,q0); r = fma(-b,q1,a); q = fma(r,y,q1)  — Markstein's
+// sequence, whose last step is provably the correctly rounded quotient given y = RN(1/b) and a faithful q1 (Markstein 1990;
+// Muller et al., Handbook of Floating-Point Arithmetic, section 4.7): bit-identical to the reference's IEEE division at 5
+// instructions instead of ~13 (no v_rcp_f64 / v_div_*).  The host enables it per AlignData only when every divisor is a
+// finite, normal, positive number of moderate magnitude; otherwise the kernel divides.  tests/test_fastdiv.py checks the
+// sequence against IEEE division on 10^8 operand pairs, including all-ones and power-of-two significands.
+//
 // Software pipeline (everything that does not depend on a neighbour runs ahead of the recurrence):
-//   head, 8 steps ahead     row / band flags of the lane on anti-diagonal s + 8 (ring of 8 entries);
-//   windows, 4-step groups  5-mer states of the lane's next four columns (one 16-byte load) and the level triple
-//                           of its row, fetched four steps before first use; a lane whose row changes inside a
-//                           window while it has a cell (only after an empty anti-diagonal) reloads directly;
-//   emission, 2 ahead       model row of the column's 5-mer from LDS (48 KB per event, transposed to 48-byte rows)
-//                           and the three IEEE divisions of cpp/AlignUtil.h:34-53;
+//   windows, 4-step groups  5-mer states of the lane's next four columns (one 16-byte load) and the level record of its
+//                           row, fetched at least three steps before first use.  A lane keeps its row for the whole window
+//                           or idles: P exceeds the widest footprint by 9, so between two rows a lane idles 9 steps;
+//   model row, 3 ahead      64-byte row {mean, 1/stdv, stdv, log stdv, sd mean, 1/sd mean, lambda, log lambda} of the
+//                           column's 5-mer from LDS (64 KB per event);
+//   emission, 2 ahead       ~30 FP64 instructions;
 //   recurrence              exchange read, ~10 additions, max chain, codes, coalesced stores, exchange write.
+// Bodies of 8 anti-diagonals near one on which the band resumes after an empty stretch (in practice: the start of the
+// sweep) — rows may then jump by any amount and take a cell at once — run a SLOW variant that recomputes rows exactly
+// and loads states / levels directly; every value is the same in both variants.
 // Column maxima (MaxInfo per column) go through an LDS ring of ds_max and are flushed to memory as columns complete.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_shr1(double v) {
@@ -223,137 +235,170 @@ __device__ __forceinline__ double wave_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
-enum : unsigned { H_INB = 1, H_TOP = 2, H_FIRST = 4, H_DEAD = 8, H_HAZ = 16 };
-constexpr int FB = 8;            // anti-diagonals per loop body = look-ahead of the head stage
-constexpr int CMAX_FLUSH = 64;   // anti-diagonals between two flushes of completed column maxima
+constexpr int FB = 8;            // anti-diagonals per loop body
+constexpr int FCH = 64;          // anti-diagonals per chunk: lo / hi prefetch unit, flush interval of the column maxima
+
+// global-memory pointers the compiler cannot trace back to a kernel argument (they come out of the job table) are
+// declared in address space 1 explicitly: otherwise every access through them is a FLAT access, which counts in both
+// vmcnt and lgkmcnt and forces "s_waitcnt vmcnt(0) lgkmcnt(0)" — i.e. a full drain of the streaming stores — per step
+#define PS_GLOBAL __attribute__((address_space(1)))
+typedef const PS_GLOBAL double* gcdp;
+typedef const PS_GLOBAL int* gcip;
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef v4i __attribute__((aligned(4))) v4i_a4;   // four states at any 4-byte aligned address
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 template <int DIR>
 struct FillState {
     double cm, cs;         // this lane's latest main / stay; -infinity while it has no cell
     double dm, de;         // upper neighbour's main (and, backward, main + emission) as read one step earlier
     double o1, o2;         // emission (+ lik_offset) of this lane's cell one / two anti-diagonals ahead
-    unsigned pf;           // head flags of the lane's previous anti-diagonal
-    int row;               // head: the lane's row on the newest anti-diagonal looked at
-    int wrow;              // head: that row at the start of the current 4-step window
-    int ri[FB];            // ring: row on anti-diagonals s .. s + 7
-    unsigned rf[FB];       // ring: flags
+    bool pin, ptop, pdead; // the lane's previous anti-diagonal: had a cell position in band / was the band's top row / invalid 5-mer
+    int row;               // the lane's row
+    int stq[4];            // states of the lane's column on anti-diagonals s .. s + 3
     int stw[2][4];         // state windows (two groups in flight)
-    double lv[2][3];       // level windows {level mean, level stdv, log stdv}
+    double lv[2][4];       // level windows {level mean, level stdv, 3 log stdv, 1 / level stdv}
+    double mr[8];          // model row of the lane's column on anti-diagonal s + 2 (read from LDS one step earlier)
+    unsigned ringat;       // byte offset of the lane's column in the column-maxima ring
 };
 
-struct __attribute__((aligned(4))) I4 { int x, y, z, w; };
-
 struct FillCtx {
-    const double* mean; const double* stdv; const double* lsd;
-    const int* st;
-    const int* LO; const int* HI;
-    double2* rec; unsigned short* flg;
-    const char* mdl;              // LDS: model rows [NS][6]
+    PS_GLOBAL const v4d* lev;     // level records of this direction: [row - 1] = {mean, stdv, 3 log stdv, 1 / stdv}
+    gcip st;
+    gcip LO; gcip HI;
+    PS_GLOBAL char* rec; PS_GLOBAL char* flg;   // anti-diagonal 0 of the job's matrix (uniform); lanes add their slot offset
+    unsigned rec_off, flg_off;    // this lane's byte offset inside an anti-diagonal
+    const char* mdl;              // LDS: model rows [NS][8]
     char* xch;                    // LDS: two exchange buffers of P records
-    unsigned long long* ring;     // LDS: column maxima, RCOLS entries
-    int ringmask;
+    char* ring;                   // LDS: column maxima, ringmask + 1 bytes
+    unsigned ringmask;
     int P, n0, C, slot;
     int wa[2], ra[2];             // byte offsets of this lane's / its upper neighbour's record in the two buffers
     double lsk, lst, lex, lin, off, log2pi;
 };
 
-template <int DIR>
-__device__ __forceinline__ double fill_emission(const FillCtx& c, int state, double x, double sd, double lsd) {
-    const char* row = c.mdl + (state < 0 ? 0 : state) * 48;
-    const double2 a = *(const double2*)row, bq = *(const double2*)(row + 16), cq = *(const double2*)(row + 32);
-    const ModelRow m = {a.x, a.y, bq.x, bq.y, cq.x, cq.y};
-    return emission(m, x, sd, lsd, c.log2pi, c.off);
+// a / b with y = RN(1 / b): Markstein's FMA sequence (see the header comment); exact IEEE quotient
+__device__ __forceinline__ double mdiv(double a, double b, double y) {
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    q = __builtin_fma(r, y, q);
+    r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
 }
 
-// level triple of row i: forward reads level i-1 but log_stdv[n0-i] (sic, cpp/Alignment.cpp:171-172); backward level n0-i
-template <int DIR>
-__device__ __forceinline__ void fill_levels(const FillCtx& c, int i, double& x, double& sd, double& lsd) {
-    const int ic = clampi(i, 1, c.n0);
-    const int tv = DIR == 0 ? ic - 1 : c.n0 - ic;
-    x = c.mean[tv]; sd = c.stdv[tv]; lsd = c.lsd[c.n0 - ic];
-}
-// state of the lane's column on anti-diagonal t, row i (any t; out-of-range columns read the -1 padding)
-template <int DIR>
-__device__ __forceinline__ int fill_state_index(const FillCtx& c, int64_t t, int i) {
-    const int64_t j = t - i;
-    const int64_t idx = DIR == 0 ? j - 1 : (int64_t)c.C - j;
-    return (int)(idx < -3 ? -3 : (idx > c.C - 1 ? c.C - 1 : idx));   // windows read [idx, idx + 3]: inside the padding
+// emission log-density (cpp/AlignUtil.h:34-38, 48-53 + cpp/Alignment.cpp:169-173), operation for operation
+// m = {mu, 1/sg, sg, log sg, sm, 1/sm, lambda, log lambda}; lev = {x, sd, 3 log sd, 1/sd}
+template <bool FASTDIV>
+__device__ __forceinline__ double fill_emission(const FillCtx& c, const double (&m)[8], const double (&lev)[4]) {
+    const double a1 = lev[0] - m[0], a2 = lev[1] - m[4];
+    const double d = FASTDIV ? mdiv(a1, m[2], m[1]) : a1 / m[2];
+    const double e = FASTDIV ? mdiv(a2, m[4], m[5]) : a2 / m[4];
+    double l = -0.5 * (d * d + c.log2pi) - m[3];
+    const double t = e * e * m[6];
+    const double q = FASTDIV ? mdiv(t, lev[1], lev[3]) : t / lev[1];
+    const double g = 0.5 * (m[7] - lev[2] - c.log2pi - q);
+    l += g;
+    l += c.off;
+    return l;
 }
 
-// one anti-diagonal.  PH = position in the loop body (compile time): ring slot, exchange buffer, window set.
-template <int DIR, int PH>
-__device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, const int64_t s, const int lo_h, const int hi_h,
-                                          const int lo_hp /* lo of anti-diagonal s + 7 */) {
+__device__ __forceinline__ void fill_model_row(const FillCtx& c, int state, double (&m)[8]) {
+    const char* row = c.mdl + (state < 0 ? 0 : state) * 64;
+    const double2 a = *(const double2*)row, bq = *(const double2*)(row + 16), cq = *(const double2*)(row + 32), dq = *(const double2*)(row + 48);
+    m[0] = a.x; m[1] = a.y; m[2] = bq.x; m[3] = bq.y; m[4] = cq.x; m[5] = cq.y; m[6] = dq.x; m[7] = dq.y;
+}
+
+__device__ __forceinline__ void fill_levels(const FillCtx& c, int i, double (&lev)[4]) {
+    const v4d v = c.lev[clampi(i, 1, c.n0) - 1];
+    lev[0] = v.x; lev[1] = v.y; lev[2] = v.z; lev[3] = v.w;
+}
+// index of the state of the lane's column on anti-diagonal t, row i (out-of-range columns read the -1 padding;
+// windows read [idx, idx + 3])
+template <int DIR>
+__device__ __forceinline__ int fill_state_index(const FillCtx& c, int t, int i) {
+    const int j = t - i;
+    const int idx = DIR == 0 ? j - 1 : c.C - j;
+    return clampi(idx, -3, c.C - 1);
+}
+// row of residue class `slot` inside [lo, lo + P)
+__device__ __forceinline__ int fill_row_of(const FillCtx& c, int lo) {
+    int d = (c.slot - lo) % c.P;
+    if (d < 0) d += c.P;
+    return lo + d;
+}
+
+// One anti-diagonal.  PH = position in the loop body (compile time): exchange buffer, window set, state queue slot.
+template <int DIR, int PH, bool SLOW, bool FASTDIV>
+__device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, const int s, const int lo_s, const int hi_s,
+                                          const bool newcol /* uniform: a column starts on this anti-diagonal */) {
     const double NINF = -__builtin_inf();
     constexpr int G = PH >> 2, K = PH & 3;
-    const int i_s = r.ri[PH];
-    const unsigned f_s = r.rf[PH];
     // ---- exchange read: what the lane one slot up published on the previous anti-diagonal
     double um, us, ue = 0.0;
     {
         const char* p = c.xch + c.ra[(PH & 1) ^ 1];
-        const double2 u = *(const double2*)p;
-        um = u.x; us = u.y;
-        if (DIR) ue = *(const double*)(p + 16);
+        if (DIR == 0) { const double2 u = *(const double2*)p; um = u.x; us = u.y; }
+        else { um = *(const double*)p; us = *(const double*)(p + 8); ue = *(const double*)(p + 16); }
     }
-    // ---- head: row and band flags of this lane on anti-diagonal s + 8
+    // ---- the lane's row and band flags on this anti-diagonal
+    int i = r.row;
     {
-        int i = r.row;
-        if (lo_h >= 0 && i < lo_h) {
-            i += c.P;
-            if (i < lo_h) {   // only after an empty stretch: the band resumes more than P rows further down
-                int d = (c.slot - lo_h) % c.P;
-                if (d < 0) d += c.P;
-                i = lo_h + d;
-            }
-        }
+        const bool behind = lo_s >= 0 && i < lo_s;
+        if (!SLOW) i = behind ? i + c.P : i;     // lo moves one row per step at most: one slot's row falls out of [lo, lo + P)
+        else if (behind) i = fill_row_of(c, lo_s);
+        if (behind) r.ringat = (unsigned)((s - i) * 8) & c.ringmask;
         r.row = i;
-        if (((PH + 2) & 3) == 0) r.wrow = i;   // s + 8 starts a window (windows are the anti-diagonals 4w .. 4w+3; s0 == 2 mod 8)
-        const bool inb = lo_h >= 0 && i <= hi_h;
-        const bool newcol = lo_hp < 0 || lo_h == lo_hp;          // uniform: a column starts on this anti-diagonal
-        unsigned f = inb ? H_INB : 0u;
-        if (inb && i == lo_h && newcol) f |= H_TOP;
-        if (inb && s + FB - i == 1) f |= H_FIRST;
-        if (inb && i != r.wrow) f |= H_HAZ;                        // row changed inside the window and the lane has a cell
-        r.ri[PH] = i; r.rf[PH] = f;
     }
-    // ---- windows: at a group start fetch the states / levels of anti-diagonals s + 6 .. s + 9
+    const bool inb = lo_s >= 0 && i <= hi_s;
+    const bool top = inb && newcol && i == lo_s;
+    const bool first = s - i == 1;
+    const bool dead = r.stq[K] < 0;
+    // ---- windows: at a group start fetch the states / levels of anti-diagonals s + 6 .. s + 9 (a window = 4w .. 4w+3; s0 == 2 mod 8)
     if (K == 0) {
-        const int wr = r.ri[(PH + 6) & 7];
-        const int64_t t0 = s + 6;
+        const int t0 = s + 6;
         if (DIR == 0) {
-            const int a = fill_state_index<0>(c, t0, wr);          // ascending with the anti-diagonal
-            const I4 v = *(const I4*)(c.st + a);                   // 4-byte aligned 16-byte load
+            const int a = fill_state_index<0>(c, t0, i);           // ascending with the anti-diagonal
+            const v4i v = *(const PS_GLOBAL v4i_a4*)(c.st + a);    // 4-byte aligned 16-byte load
             r.stw[G][0] = v.x; r.stw[G][1] = v.y; r.stw[G][2] = v.z; r.stw[G][3] = v.w;
         } else {
-            const int a = fill_state_index<1>(c, t0 + 3, wr);      // descending: element 3 - k belongs to step t0 + k
-            const I4 v = *(const I4*)(c.st + a);
+            const int a = fill_state_index<1>(c, t0 + 3, i);       // descending: element 3 - k belongs to step t0 + k
+            const v4i v = *(const PS_GLOBAL v4i_a4*)(c.st + a);
             r.stw[G][0] = v.w; r.stw[G][1] = v.z; r.stw[G][2] = v.y; r.stw[G][3] = v.x;
         }
-        fill_levels<DIR>(c, wr, r.lv[G][0], r.lv[G][1], r.lv[G][2]);
+        fill_levels(c, i, r.lv[G]);
     }
-    // ---- emission of anti-diagonal s + 2 (window fetched at the previous group start)
+    // ---- emission of anti-diagonal s + 2: its model row arrived during the previous step; levels from the window the
+    //      previous group start fetched (set G ^ 1)
     double o_new;
     {
-        constexpr int M = (PH + 2) & 7;           // ring slot of s + 2
-        // s + 2 is element K of the window [4w, 4w+3] that the previous group start fetched (into set G ^ 1)
-        constexpr int SET = G ^ 1;
-        int state = r.stw[SET][K];
-        double x = r.lv[SET][0], sd = r.lv[SET][1], lsd = r.lv[SET][2];
-        if (r.rf[M] & H_HAZ) {                    // rare: direct loads for the lane's actual row
-            const int im = r.ri[M];
-            state = c.st[fill_state_index<DIR>(c, s + 2, im)];
-            fill_levels<DIR>(c, im, x, sd, lsd);
+        if (!SLOW) o_new = fill_emission<FASTDIV>(c, r.mr, r.lv[G ^ 1]);
+        else {
+            const int lo2 = s + 2 >= 0 ? c.LO[s + 2] : -1;
+            double lev[4];
+            fill_levels(c, lo2 >= 0 ? fill_row_of(c, lo2) : i, lev);
+            o_new = fill_emission<FASTDIV>(c, r.mr, lev);
         }
-        if (state < 0) r.rf[M] |= H_DEAD;
-        o_new = fill_emission<DIR>(c, state, x, sd, lsd);
+    }
+    // ---- model row of anti-diagonal s + 3: its state is element (PH + 1) & 3 of the window [4w, 4w+3] holding s + 3,
+    //      fetched at body offset 4w - 6: the previous body's second group (set 1), this body's first (0) or second (1).
+    //      (Handing the rows down the lanes with DPP instead of gathering them — lane L+1 needs on step s+1 the row lane L
+    //      used on step s — removes the LDS bank conflicts of the gather, 71 % of the LDS cycles, but costs 16 more VALU
+    //      instructions per step and the kernel is VALU-issue bound: measured 13.3 ms against 12.2 ms per 10 kb fill.)
+    {
+        constexpr int SET = (PH <= 2 || PH == 7) ? 1 : 0;
+        int state = r.stw[SET][(PH + 1) & 3];
+        if (SLOW) {
+            const int lo3 = s + 3 >= 0 ? c.LO[s + 3] : -1;
+            state = c.st[fill_state_index<DIR>(c, s + 3, lo3 >= 0 ? fill_row_of(c, lo3) : i)];
+        }
+        r.stq[(PH + 3) & 3] = state;
+        fill_model_row(c, state, r.mr);
     }
     // ---- recurrence on anti-diagonal s
     {
-        const bool inb = f_s & H_INB, top = f_s & H_TOP, first = f_s & H_FIRST, dead = f_s & H_DEAD;
-        const bool pin = r.pf & H_INB;
-        const bool vd = first || (pin && !(r.pf & H_TOP));
-        const bool rd = vd && !first && !(r.pf & H_DEAD);
+        const bool vd = first || (r.pin && !r.ptop);
+        const bool rd = !first && r.pin && !r.ptop && !r.pdead;
         const double o = r.o1;
         double L;   // max(cm, 0) in one instruction (fmax() would first canonicalise its operand)
         asm("v_max_f64 %0, %1, 0" : "=v"(L) : "v"(r.cm));
@@ -375,10 +420,12 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
         const bool act = inb && !dead;
         r.cm = act ? nm : NINF;
         r.cs = act ? ns : NINF;
-        // stored record: the cell, zeros for a cell of an invalid-5-mer column (cpp/Alignment.cpp:162-163)
-        const double2 recv = make_double2(act ? nm : (inb ? 0.0 : NINF), act ? ns : (inb ? 0.0 : NINF));
-        const int64_t cell = s * c.P + c.slot;
-        c.rec[cell] = recv;
+        // stored record: the cell; zeros for a cell of an invalid-5-mer column (cpp/Alignment.cpp:162-163) and, harmlessly,
+        // for slots outside the band (nm >= 0, and the stay value of a top row is -1e300 and must stay so)
+        double rx;
+        asm("v_max_f64 %0, %1, 0" : "=v"(rx) : "v"(r.cm));
+        const uint64_t sP = (uint64_t)(unsigned)(s + MAT_FRONT) * (unsigned)c.P;   // uniform
+        *(PS_GLOBAL v2d*)(c.rec + sP * 16 + c.rec_off) = (v2d){rx, act ? ns : 0.0};
         if (DIR == 0) {
             // back-pointer codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order
             unsigned ss = cSTAY > floor_s ? M_STAY : 0u;
@@ -391,94 +438,133 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
             sm = nm > 0.0 ? sm : 0u;
             // bits 14 / 15: main / stay score <= 0 (the backtrace stops there, cpp/Alignment.cpp:542)
             const unsigned w = sm | (ss << 8) | (nm > 0.0 ? 0u : 0x4000u) | (ns > 0.0 ? 0u : 0x8000u);
-            c.flg[cell] = (unsigned short)(act ? w : FLG_DEAD);
+            *(PS_GLOBAL unsigned short*)(c.flg + sP * 2 + c.flg_off) = (unsigned short)(act ? w : FLG_DEAD);
         }
         // publish for the lane one slot down
         char* q = c.xch + c.wa[PH & 1];
         if (DIR == 0) {
             *(double2*)q = make_double2(r.cm, r.cs);
         } else {
-            *(double2*)q = make_double2(r.cm, r.cs + o);
-            *(double*)(q + 16) = r.cm + o;
+            *(double*)q = r.cm; *(double*)(q + 8) = r.cs + o; *(double*)(q + 16) = r.cm + o;
         }
-        // column maximum (scores are >= 0: their bit patterns order like unsigned integers)
-        if (act && nm > 0.0) atomicMax(&c.ring[(unsigned)(s - i_s) & c.ringmask], (unsigned long long)__double_as_longlong(nm));
+        // column maximum (scores are >= 0: their bit patterns order like unsigned integers; 0 is a no-op)
+        atomicMax((unsigned long long*)(c.ring + r.ringat), (unsigned long long)__double_as_longlong(rx));
+        r.ringat = (r.ringat + 8) & c.ringmask;
         r.dm = um; r.de = ue;
-        r.pf = f_s;
+        r.pin = inb; r.ptop = top; r.pdead = dead;
     }
     r.o1 = r.o2; r.o2 = o_new;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int DIR>
-__device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* smem, const int rcols) {
+template <int DIR, bool SLOW, bool FASTDIV>
+__device__ __forceinline__ void fill_group8(FillState<DIR>& r, const FillCtx& c, const int s0, const int (&lov)[FB], const int (&hiv)[FB], const int lo_p) {
+#define PS_NEWCOL(k, prev) ((prev) < 0 || lov[k] == (prev))
+    fill_step<DIR, 0, SLOW, FASTDIV>(r, c, s0 + 0, lov[0], hiv[0], PS_NEWCOL(0, lo_p));
+    fill_step<DIR, 1, SLOW, FASTDIV>(r, c, s0 + 1, lov[1], hiv[1], PS_NEWCOL(1, lov[0]));
+    fill_step<DIR, 2, SLOW, FASTDIV>(r, c, s0 + 2, lov[2], hiv[2], PS_NEWCOL(2, lov[1]));
+    fill_step<DIR, 3, SLOW, FASTDIV>(r, c, s0 + 3, lov[3], hiv[3], PS_NEWCOL(3, lov[2]));
+    fill_step<DIR, 4, SLOW, FASTDIV>(r, c, s0 + 4, lov[4], hiv[4], PS_NEWCOL(4, lov[3]));
+    fill_step<DIR, 5, SLOW, FASTDIV>(r, c, s0 + 5, lov[5], hiv[5], PS_NEWCOL(5, lov[4]));
+    fill_step<DIR, 6, SLOW, FASTDIV>(r, c, s0 + 6, lov[6], hiv[6], PS_NEWCOL(6, lov[5]));
+    fill_step<DIR, 7, SLOW, FASTDIV>(r, c, s0 + 7, lov[7], hiv[7], PS_NEWCOL(7, lov[6]));
+#undef PS_NEWCOL
+}
+
+constexpr int FILL_MODEL_BYTES = 8 * NS * (int)sizeof(double);
+
+template <int DIR, bool FASTDIV>
+__device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* smem, const int rcols, const int slowwords) {
     const int P = J.P, slot = threadIdx.x;
     FillCtx c;
-    c.mean = J.mean; c.stdv = J.stdv; c.lsd = J.lsd; c.st = J.st;
-    c.LO = b.lo + J.lo_off[DIR]; c.HI = b.hi + J.lo_off[DIR];
-    c.rec = b.rec + J.mat_off[DIR]; c.flg = b.flg + J.mat_off[DIR];
+    c.lev = (PS_GLOBAL const v4d*)J.lev[DIR]; c.st = (gcip)J.st;
+    c.LO = (gcip)(b.lo + J.lo_off[DIR]); c.HI = (gcip)(b.hi + J.lo_off[DIR]);
+    c.rec = (PS_GLOBAL char*)(b.rec + J.mat_off[DIR] - (int64_t)MAT_FRONT * P); c.flg = (PS_GLOBAL char*)(b.flg + J.mat_off[DIR] - (int64_t)MAT_FRONT * P);
+    c.rec_off = (unsigned)slot * 16u; c.flg_off = (unsigned)slot * 2u;
     c.P = P; c.n0 = J.n0; c.C = J.C; c.slot = slot;
     c.lsk = J.lsk; c.lst = J.lst; c.lex = J.lex; c.lin = J.lin; c.off = J.lik_offset; c.log2pi = b.log2pi;
-    constexpr int RB = DIR ? 32 : 16;   // bytes per exchanged record: {main, stay} / {main, stay + em, main + em, -}
-    double* s_model = (double*)smem;
+    constexpr int RB = DIR ? 24 : 16;   // bytes per exchanged record: {main, stay} / {main, stay + em, main + em}
     c.mdl = smem;
-    c.xch = smem + 6 * NS * sizeof(double);
-    c.ring = (unsigned long long*)(c.xch + 2 * P * 32);
-    c.ringmask = rcols - 1;
-    // the event's model, transposed to one 48-byte row per 5-mer
-    for (int k = slot; k < 6 * NS; k += P) s_model[(k & (NS - 1)) * 6 + (k >> 10)] = J.model[k];
-    for (int k = slot; k < rcols; k += P) c.ring[k] = 0ull;
+    c.xch = smem + FILL_MODEL_BYTES;
+    c.ring = c.xch + 2 * P * 24;
+    c.ringmask = (unsigned)rcols * 8u - 1u;
+    unsigned* slowmap = (unsigned*)(c.ring + rcols * 8);
+    // the event's model rows (64 bytes per 5-mer, laid out by the host)
+    {
+        const double2* src = (const double2*)J.model8;
+        double2* dst = (double2*)smem;
+        for (int k = slot; k < 4 * NS; k += P) dst[k] = src[k];
+    }
+    for (int k = slot; k < rcols; k += P) ((unsigned long long*)c.ring)[k] = 0ull;
+    for (int k = slot; k < slowwords; k += P) slowmap[k] = 0u;
     const int up_slot = slot == 0 ? P - 1 : slot - 1;
     const double NINF = -__builtin_inf();
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         c.wa[k] = (k * P + slot) * RB;
         c.ra[k] = (k * P + up_slot) * RB;
-        *(double2*)(c.xch + c.wa[k]) = make_double2(NINF, NINF);
+        *(double*)(c.xch + c.wa[k]) = NINF; *(double*)(c.xch + c.wa[k] + 8) = NINF;
         if (DIR) *(double*)(c.xch + c.wa[k] + 16) = NINF;
     }
+    const int S = (int)J.S;
+    const int s_first = 2 - FB;                          // the pipeline needs a few steps to fill; they fall into the front padding
+    __syncthreads();
+    // bodies that must run the SLOW variant: the band resumes on anti-diagonal t (lo(t-1) < 0 <= lo(t)).  Windows fetched on
+    // t - 9 .. t - 1 hold the states / levels of rows that may no longer be the lane's; they are consumed on t - 6 .. t + 6
+    for (int t = 2 + slot; t < S; t += P) {
+        if (c.LO[t] >= 0 && c.LO[t - 1] < 0) {
+            const int b0 = max(0, (t - 6 - s_first) >> 3), b1 = (t + 6 - s_first) >> 3;
+            for (int bb = b0; bb <= b1; bb++) atomicOr(&slowmap[bb >> 5], 1u << (bb & 31));
+        }
+    }
     FillState<DIR> r;
-    r.cm = NINF; r.cs = NINF; r.dm = NINF; r.de = NINF; r.o1 = 0.0; r.o2 = 0.0; r.pf = 0;
+    r.cm = NINF; r.cs = NINF; r.dm = NINF; r.de = NINF; r.o1 = 0.0; r.o2 = 0.0;
+    r.pin = false; r.ptop = false; r.pdead = false;
     r.row = slot == 0 ? P : slot;   // rows start at 1: the smallest row of this slot's residue class
-    r.wrow = r.row;
+    r.ringat = (unsigned)((s_first - r.row) * 8) & c.ringmask;
 #pragma unroll
-    for (int k = 0; k < FB; k++) { r.ri[k] = r.row; r.rf[k] = 0; }
+    for (int k = 0; k < 4; k++) r.stq[k] = 0;
 #pragma unroll
     for (int g = 0; g < 2; g++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) r.stw[g][k] = 0;
-        r.lv[g][0] = 0.0; r.lv[g][1] = 1.0; r.lv[g][2] = 0.0;
+        r.lv[g][0] = 0.0; r.lv[g][1] = 1.0; r.lv[g][2] = 0.0; r.lv[g][3] = 1.0;
     }
+    r.mr[0] = 0.0; r.mr[1] = 1.0; r.mr[2] = 1.0; r.mr[3] = 0.0; r.mr[4] = 1.0; r.mr[5] = 1.0; r.mr[6] = 0.0; r.mr[7] = 0.0;
     __syncthreads();
 
-    const int64_t S = J.S;
-    const int64_t s_first = 2 - FB;                      // the pipeline needs FB steps to fill; they fall into the front padding
     int flushed = 1;                                     // columns below this have their maximum in memory
     double* gcmax = b.cmax + J.col_off[DIR];
-    int lo_hp = -1;                                      // lo of the anti-diagonal before the head's
-    for (int64_t s0 = s_first; s0 < S; s0 += FB) {
-        // lo / hi of the anti-diagonals the head stages of this body look at (uniform: scalar loads)
-        int lov[FB], hiv[FB];
+    int lo_p = -1;                                       // lo of the previous anti-diagonal
+    const int lane = slot & 63;
+    // lo / hi of 64 anti-diagonals per VGPR (lane k holds entry k), fetched one chunk ahead
+    int loc = c.LO[max(s_first + lane, 0)], hic = c.HI[max(s_first + lane, 0)];
+    if (s_first + lane < 0) { loc = -1; hic = -1; }
+    int nbody = 0;
+    for (int cb = s_first; cb < S; cb += FCH) {
+        const int lon = c.LO[min(cb + FCH + lane, S + LO_PAD - 1)], hin = c.HI[min(cb + FCH + lane, S + LO_PAD - 1)];
+#pragma unroll 1
+        for (int o = 0; o < FCH && cb + o < S; o += FB, nbody++) {
+            const int s0 = cb + o;
+            int lov[FB], hiv[FB];
 #pragma unroll
-        for (int k = 0; k < FB; k++) { lov[k] = c.LO[s0 + FB + k]; hiv[k] = c.HI[s0 + FB + k]; }
-        fill_step<DIR, 0>(r, c, s0 + 0, lov[0], hiv[0], lo_hp);
-        fill_step<DIR, 1>(r, c, s0 + 1, lov[1], hiv[1], lov[0]);
-        fill_step<DIR, 2>(r, c, s0 + 2, lov[2], hiv[2], lov[1]);
-        fill_step<DIR, 3>(r, c, s0 + 3, lov[3], hiv[3], lov[2]);
-        fill_step<DIR, 4>(r, c, s0 + 4, lov[4], hiv[4], lov[3]);
-        fill_step<DIR, 5>(r, c, s0 + 5, lov[5], hiv[5], lov[4]);
-        fill_step<DIR, 6>(r, c, s0 + 6, lov[6], hiv[6], lov[5]);
-        fill_step<DIR, 7>(r, c, s0 + 7, lov[7], hiv[7], lov[6]);
-        lo_hp = lov[7];
+            for (int k = 0; k < FB; k++) { lov[k] = __builtin_amdgcn_readlane(loc, o + k); hiv[k] = __builtin_amdgcn_readlane(hic, o + k); }
+            const unsigned sw = __builtin_amdgcn_readfirstlane(slowmap[nbody >> 5]);
+            if ((sw >> (nbody & 31)) & 1u) fill_group8<DIR, true, FASTDIV>(r, c, s0, lov, hiv, lo_p);
+            else fill_group8<DIR, false, FASTDIV>(r, c, s0, lov, hiv, lo_p);
+            lo_p = lov[FB - 1];
+        }
+        loc = lon; hic = hin;
         // flush the maxima of completed columns: every column left of the oldest one still present on the next anti-diagonal
-        if ((((s0 - s_first) / FB) & (CMAX_FLUSH / FB - 1)) == CMAX_FLUSH / FB - 1) {
-            const int64_t sn = s0 + FB;
-            const int lo_n = c.LO[sn], hi_n = c.HI[sn];
-            if (lo_n >= 0) {
-                const int jdone = (int)(sn - hi_n);      // oldest column still present
+        {
+            const int sn = cb + FCH;
+            const int lo_n = __builtin_amdgcn_readlane(loc, 0), hi_n = __builtin_amdgcn_readlane(hic, 0);
+            if (sn < S && lo_n >= 0) {
+                const int jdone = sn - hi_n;             // oldest column still present
                 for (int col = flushed + slot; col < jdone; col += P) {
-                    const unsigned long long v = c.ring[col & c.ringmask];
-                    c.ring[col & c.ringmask] = 0ull;
+                    unsigned long long* e = (unsigned long long*)(c.ring + (((unsigned)col * 8u) & c.ringmask));
+                    const unsigned long long v = *e;
+                    *e = 0ull;
                     gcmax[col] = __longlong_as_double((long long)v);
                 }
                 flushed = max(flushed, jdone);
@@ -486,18 +572,19 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* 
         }
     }
     __syncthreads();
-    for (int col = flushed + slot; col <= J.C; col += P) gcmax[col] = __longlong_as_double((long long)c.ring[col & c.ringmask]);
+    for (int col = flushed + slot; col <= J.C; col += P)
+        gcmax[col] = __longlong_as_double((long long)*(unsigned long long*)(c.ring + (((unsigned)col * 8u) & c.ringmask)));
 }
 
-// MAXT = 512 lets the compiler keep the whole pipeline in registers (LDS already limits a CU to two such workgroups);
-// bands wider than 512 slots take the 1024-thread build
-template <int MAXT>
-__global__ __launch_bounds__(MAXT) void k_fill(BatchD b, int ndir, int rcols) {
+// MAXT = 512 lets the compiler keep the whole pipeline in registers; bands wider than 512 slots take the 1024-thread build
+// FASTDIV: tabulated reciprocals (the normal case) or IEEE divisions (some divisor of the AlignData is not a sane number)
+template <int MAXT, bool FASTDIV>
+__global__ __launch_bounds__(MAXT) void k_fill(BatchD b, int ndir, int rcols, int slowwords) {
     extern __shared__ double2 fill_smem[];
     const int jd = blockIdx.x, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
     if (J.out->inert) return;
-    if (dir == 0) fill_body<0>(b, J, (char*)fill_smem, rcols); else fill_body<1>(b, J, (char*)fill_smem, rcols);
+    if (dir == 0) fill_body<0, FASTDIV>(b, J, (char*)fill_smem, rcols, slowwords); else fill_body<1, FASTDIV>(b, J, (char*)fill_smem, rcols, slowwords);
 }
 
 // prefix max over columns + (fwd) the first cell achieving the global max ; grid njobs*ndir, block 64
@@ -903,23 +990,36 @@ int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS) {
     return PS_OK;
 }
 
-// LDS of one k_fill workgroup: the event's model (48 KB), two exchange buffers, the column-maxima ring
-static int fill_ring_cols(int P) { return P + 128 <= 1024 ? 1024 : (P + 128 <= 2048 ? 2048 : 4096); }
-static size_t fill_lds_bytes(int P) { return 6 * NS * sizeof(double) + (size_t)2 * P * 32 + (size_t)fill_ring_cols(P) * 8; }
+// LDS of one k_fill workgroup: the event's model rows (64 KB), two exchange buffers, the column-maxima ring, the slow-body bitmap
+static int fill_ring_cols(int P) { return P + 96 <= 512 ? 512 : (P + 96 <= 1024 ? 1024 : 2048); }
+static int fill_slow_words(int64_t maxS) { return (int)((maxS + 2 * FB) / FB / 32 + 2); }
+static size_t fill_lds_bytes(int P, int64_t maxS) {
+    return FILL_MODEL_BYTES + (size_t)2 * P * 24 + (size_t)fill_ring_cols(P) * 8 + (size_t)fill_slow_words(maxS) * 4;
+}
 
 int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols) {
     if (!b.njobs) return PS_OK;
-    (void)maxS;
     static bool attr_set = false;   // more than the default 64 KB of dynamic LDS needs the attribute (idempotent; racing threads set the same value)
     if (!attr_set) {
-        PS_HIP(hipFuncSetAttribute((const void*)k_fill<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PS_HIP(hipFuncSetAttribute((const void*)k_fill<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PS_HIP(hipFuncSetAttribute((const void*)k_fill<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PS_HIP(hipFuncSetAttribute((const void*)k_fill<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PS_HIP(hipFuncSetAttribute((const void*)k_fill<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PS_HIP(hipFuncSetAttribute((const void*)k_fill<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     PS_HIP(hipMemsetAsync(b.cmax, 0, ncols * sizeof(double), rt->stream));
+    const size_t lds = fill_lds_bytes(P, maxS);
+    if (lds > 160 * 1024) return fail(PS_ERR_UNSUPPORTED, "alignment too long for the fill kernel's LDS bitmap");
     prof_begin(rt);
-    if (P <= 512) hipLaunchKernelGGL(k_fill<512>, dim3(b.njobs * ndir), dim3(P), fill_lds_bytes(P), rt->stream, b, ndir, fill_ring_cols(P));
-    else hipLaunchKernelGGL(k_fill<1024>, dim3(b.njobs * ndir), dim3(P), fill_lds_bytes(P), rt->stream, b, ndir, fill_ring_cols(P));
+    const dim3 grid(b.njobs * ndir), block(P);
+    const int rc = fill_ring_cols(P), sw = fill_slow_words(maxS);
+    if (b.fastdiv) {
+        if (P <= 512) hipLaunchKernelGGL((k_fill<512, true>), grid, block, lds, rt->stream, b, ndir, rc, sw);
+        else hipLaunchKernelGGL((k_fill<1024, true>), grid, block, lds, rt->stream, b, ndir, rc, sw);
+    } else {
+        if (P <= 512) hipLaunchKernelGGL((k_fill<512, false>), grid, block, lds, rt->stream, b, ndir, rc, sw);
+        else hipLaunchKernelGGL((k_fill<1024, false>), grid, block, lds, rt->stream, b, ndir, rc, sw);
+    }
     PS_LAUNCH_CHECK();
     prof_end(rt, "fill", 0.0);
     hipLaunchKernelGGL(k_prefix, dim3(b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
