@@ -239,7 +239,7 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
         memset(&j, 0, sizeof(j));
         j.mean = a->d_mean + a->off[s.ev]; j.stdv = a->d_stdv + a->off[s.ev]; j.lsd = a->d_lsd + a->off[s.ev];
         j.model = a->d_model + (size_t)s.ev * 6 * NS;
-        j.model8 = a->d_model8 + (size_t)s.ev * 8 * NS;
+        j.model8 = a->d_model8 + (size_t)s.ev * (MODEL_ROW_BYTES / 8) * NS;
         j.lev[0] = a->d_lev[0] + 4 * a->off[s.ev]; j.lev[1] = a->d_lev[1] + 4 * a->off[s.ev];
         if (!a->fastdiv) d.fastdiv = 0;
         j.lsk = a->h_trans[s.ev * 4 + 0]; j.lst = a->h_trans[s.ev * 4 + 1]; j.lex = a->h_trans[s.ev * 4 + 2]; j.lin = a->h_trans[s.ev * 4 + 3];
@@ -360,15 +360,15 @@ int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_event
     h_trans = tr;
     // k_fill's tables: model rows with the reciprocals of the two model divisors, level records per direction with the
     // reciprocal of the level stdv (correctly rounded: host IEEE division)
-    std::vector<double> mdl8((size_t)E * 8 * NS), lev((size_t)2 * 4 * std::max<int64_t>(ntot, 1));
+    std::vector<double> mdl8((size_t)E * (MODEL_ROW_BYTES / 8) * NS), lev((size_t)2 * 4 * std::max<int64_t>(ntot, 1));
     auto sane = [](double v) { return std::isfinite(v) && v > 1e-100 && v < 1e100; };
     fastdiv = true;
     for (int e = 0; e < E; e++) {
         const double* d6 = mdl.data() + (size_t)e * 6 * NS;
-        double* d8 = mdl8.data() + (size_t)e * 8 * NS;
+        double* d8 = mdl8.data() + (size_t)e * (MODEL_ROW_BYTES / 8) * NS;
         for (int k = 0; k < NS; k++) {
             const double lm = d6[k], ls = d6[NS + k], sm = d6[3 * NS + k], lam = d6[4 * NS + k];
-            double* r8 = d8 + (size_t)k * 8;
+            double* r8 = d8 + (size_t)k * (MODEL_ROW_BYTES / 8);
             r8[0] = lm; r8[1] = 1.0 / ls; r8[2] = ls; r8[3] = d6[2 * NS + k];
             r8[4] = sm; r8[5] = 1.0 / sm; r8[6] = lam; r8[7] = d6[5 * NS + k];
             if (!sane(ls) || !sane(sm) || !std::isfinite(lm) || !std::isfinite(lam) || std::fabs(lm) > 1e100 || std::fabs(lam) > 1e100) fastdiv = false;
@@ -459,7 +459,7 @@ int realign(Runtime* rt, Batch& b) {
     // window of k_fill (fetched six steps ahead, four steps long) never spans two rows of a lane that has a cell
     PS_TRY(b.place(rt, std::max(*w, 1) + 9));
     if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes();
-    PS_TRY(launch_fill(rt, b.d, b.ndir, b.maxS, b.P, b.ncols));
+    PS_TRY(launch_fill(rt, b.d, b.jobs, b.ndir, b.maxS, b.P, b.ncols));
     PS_TRY(launch_backtrace(rt, b.d, b.maxn));
     PS_TRY(launch_updaterefs(rt, b.d));
     return PS_OK;

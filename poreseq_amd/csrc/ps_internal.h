@@ -117,7 +117,7 @@ struct JobD {
     const double* stdv;
     const double* lsd;    // log(stdv), host libm
     const double* model;  // derived model of the event, [6][1024]: lev_mean, lev_stdv, log_lev, sd_mean, sd_lambda, log_lambda
-    const double* model8; // the same per 5-mer, [1024][8]: mean, 1/stdv, stdv, log stdv, sd mean, 1/sd mean, lambda, log lambda (k_fill)
+    const double* model8; // the same per 5-mer, rows of MODEL_ROW_BYTES: mean, 1/stdv, stdv, log stdv, sd mean, 1/sd mean, lambda, log lambda (k_fill)
     const double* lev[2]; // level records per direction, [n0][4]: forward row i -> {mean[i-1], stdv[i-1], 3 lsd[n0-i], 1/stdv[i-1]},
                           //                                      backward row i -> the same of level n0-i (cpp/Alignment.cpp:171-172, 345-349)
     const int* st;        // 5-mer states of the job's sequence [C] (4 ints of -1 padding on either side)
@@ -152,6 +152,7 @@ struct JobOut {
     int pad0, pad1;
 };
 
+constexpr int MODEL_ROW_BYTES = 80;   // k_fill's model rows: 8 doubles + 16 bytes of padding (LDS bank spread)
 constexpr int MAT_FRONT = 8;   // spare anti-diagonals in front of every matrix (the fill pipeline starts 8 steps early)
 constexpr int MAT_BACK = 16;   // and behind it (the last loop body runs past S)
 constexpr int LO_PAD = 160;    // LO / HI entries behind S, all -1 (k_fill prefetches them in chunks of 64)
@@ -176,7 +177,7 @@ struct BatchD {
 int launch_updaterefs(Runtime* rt, const BatchD& b);
 int launch_lb(Runtime* rt, const BatchD& b, int which /*0: lb_off, 1: lbn_off*/, int maxlbn);
 int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS);
-int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols);
+int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int ndir, int64_t maxS, int P, int64_t ncols);
 int launch_backtrace(Runtime* rt, const BatchD& b, int maxn);
 
 struct ScoreArgs {

@@ -24,6 +24,8 @@
 //   k_backtrace   LDS-tile walker with wave-wide look-ahead and tile prefetch, then k_fill_like, k_updaterefs /
 //                 k_lb for the new band centres
 //   k_old / k_score / k_reduce   edit scoring (scoreMutation + columnMax) and the per-edit sums
+#include <algorithm>
+
 #include "ps_internal.h"
 
 namespace ps {
@@ -273,7 +275,7 @@ struct FillCtx {
     char* xch;                    // LDS: two exchange buffers of P records
     char* ring;                   // LDS: column maxima, ringmask + 1 bytes
     unsigned ringmask;
-    int P, n0, C, slot;
+    int P, n0, C, slot, S;
     int wa[2], ra[2];             // byte offsets of this lane's / its upper neighbour's record in the two buffers
     double lsk, lst, lex, lin, off, log2pi;
 };
@@ -304,7 +306,9 @@ __device__ __forceinline__ double fill_emission(const FillCtx& c, const double (
 }
 
 __device__ __forceinline__ void fill_model_row(const FillCtx& c, int state, double (&m)[8]) {
-    const char* row = c.mdl + (state < 0 ? 0 : state) * 64;
+    // rows are 80 bytes apart: with 64 the k-th quarter of every row falls on 4 of the 16 four-bank groups (ds_read_b128 of 64
+    // random rows: 71 % conflict cycles measured), with 80 on all 16
+    const char* row = c.mdl + (state < 0 ? 0 : state) * MODEL_ROW_BYTES;
     const double2 a = *(const double2*)row, bq = *(const double2*)(row + 16), cq = *(const double2*)(row + 32), dq = *(const double2*)(row + 48);
     m[0] = a.x; m[1] = a.y; m[2] = bq.x; m[3] = bq.y; m[4] = cq.x; m[5] = cq.y; m[6] = dq.x; m[7] = dq.y;
 }
@@ -374,12 +378,14 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
     {
         if (!SLOW) o_new = fill_emission<FASTDIV>(c, r.mr, r.lv[G ^ 1]);
         else {
-            const int lo2 = s + 2 >= 0 ? c.LO[s + 2] : -1;
+            const int lo2 = (s + 2 >= 0 && s + 2 < c.S) ? c.LO[s + 2] : -1;
             double lev[4];
             fill_levels(c, lo2 >= 0 ? fill_row_of(c, lo2) : i, lev);
             o_new = fill_emission<FASTDIV>(c, r.mr, lev);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);   // stage fence: with three waves per SIMD the other waves hide latency; keeping the
+                                         // stages apart keeps their temporaries from piling up (168 VGPRs for 12 waves per CU)
     // ---- model row of anti-diagonal s + 3: its state is element (PH + 1) & 3 of the window [4w, 4w+3] holding s + 3,
     //      fetched at body offset 4w - 6: the previous body's second group (set 1), this body's first (0) or second (1).
     //      (Handing the rows down the lanes with DPP instead of gathering them — lane L+1 needs on step s+1 the row lane L
@@ -389,12 +395,13 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
         constexpr int SET = (PH <= 2 || PH == 7) ? 1 : 0;
         int state = r.stw[SET][(PH + 1) & 3];
         if (SLOW) {
-            const int lo3 = s + 3 >= 0 ? c.LO[s + 3] : -1;
+            const int lo3 = (s + 3 >= 0 && s + 3 < c.S) ? c.LO[s + 3] : -1;
             state = c.st[fill_state_index<DIR>(c, s + 3, lo3 >= 0 ? fill_row_of(c, lo3) : i)];
         }
         r.stq[(PH + 3) & 3] = state;
         fill_model_row(c, state, r.mr);
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- recurrence on anti-diagonal s
     {
         const bool vd = first || (r.pin && !r.ptop);
@@ -424,7 +431,8 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
         // for slots outside the band (nm >= 0, and the stay value of a top row is -1e300 and must stay so)
         double rx;
         asm("v_max_f64 %0, %1, 0" : "=v"(rx) : "v"(r.cm));
-        const uint64_t sP = (uint64_t)(unsigned)(s + MAT_FRONT) * (unsigned)c.P;   // uniform
+        // (a half whose sweep is shorter than its partner's keeps stepping: its idle records go to the last padding row)
+        const uint64_t sP = (uint64_t)(unsigned)(min(s, c.S + MAT_BACK - 1) + MAT_FRONT) * (unsigned)c.P;   // uniform
         *(PS_GLOBAL v2d*)(c.rec + sP * 16 + c.rec_off) = (v2d){rx, act ? ns : 0.0};
         if (DIR == 0) {
             // back-pointer codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order
@@ -471,11 +479,15 @@ __device__ __forceinline__ void fill_group8(FillState<DIR>& r, const FillCtx& c,
 #undef PS_NEWCOL
 }
 
-constexpr int FILL_MODEL_BYTES = 8 * NS * (int)sizeof(double);
+constexpr int FILL_MODEL_BYTES = MODEL_ROW_BYTES * NS;
 
+// One half of a k_fill workgroup: the sweep of one (job, direction).  `slot` is the thread's lane inside the half, `hsm` the
+// half's private LDS (exchange buffers, ring, bitmap), `model` the workgroup's shared model rows, Smax the longer of the two
+// sweeps of the workgroup (both halves execute the same number of barriers).
 template <int DIR, bool FASTDIV>
-__device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* smem, const int rcols, const int slowwords) {
-    const int P = J.P, slot = threadIdx.x;
+__device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const char* model, char* hsm, const int slot, const int Smax,
+                                          const int rcols, const int slowwords) {
+    const int P = J.P;
     FillCtx c;
     c.lev = (PS_GLOBAL const v4d*)J.lev[DIR]; c.st = (gcip)J.st;
     c.LO = (gcip)(b.lo + J.lo_off[DIR]); c.HI = (gcip)(b.hi + J.lo_off[DIR]);
@@ -484,17 +496,11 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* 
     c.P = P; c.n0 = J.n0; c.C = J.C; c.slot = slot;
     c.lsk = J.lsk; c.lst = J.lst; c.lex = J.lex; c.lin = J.lin; c.off = J.lik_offset; c.log2pi = b.log2pi;
     constexpr int RB = DIR ? 24 : 16;   // bytes per exchanged record: {main, stay} / {main, stay + em, main + em}
-    c.mdl = smem;
-    c.xch = smem + FILL_MODEL_BYTES;
+    c.mdl = model;
+    c.xch = hsm;
     c.ring = c.xch + 2 * P * 24;
     c.ringmask = (unsigned)rcols * 8u - 1u;
     unsigned* slowmap = (unsigned*)(c.ring + rcols * 8);
-    // the event's model rows (64 bytes per 5-mer, laid out by the host)
-    {
-        const double2* src = (const double2*)J.model8;
-        double2* dst = (double2*)smem;
-        for (int k = slot; k < 4 * NS; k += P) dst[k] = src[k];
-    }
     for (int k = slot; k < rcols; k += P) ((unsigned long long*)c.ring)[k] = 0ull;
     for (int k = slot; k < slowwords; k += P) slowmap[k] = 0u;
     const int up_slot = slot == 0 ? P - 1 : slot - 1;
@@ -506,8 +512,9 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* 
         *(double*)(c.xch + c.wa[k]) = NINF; *(double*)(c.xch + c.wa[k] + 8) = NINF;
         if (DIR) *(double*)(c.xch + c.wa[k] + 16) = NINF;
     }
-    const int S = (int)J.S;
+    const int S = (int)J.S;                              // this half's sweep; the loops below run to Smax >= S (idle steps past S)
     const int s_first = 2 - FB;                          // the pipeline needs a few steps to fill; they fall into the front padding
+    c.S = S;
     __syncthreads();
     // bodies that must run the SLOW variant: the band resumes on anti-diagonal t (lo(t-1) < 0 <= lo(t)).  Windows fetched on
     // t - 9 .. t - 1 hold the states / levels of rows that may no longer be the lane's; they are consumed on t - 6 .. t + 6
@@ -541,10 +548,10 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* 
     int loc = c.LO[max(s_first + lane, 0)], hic = c.HI[max(s_first + lane, 0)];
     if (s_first + lane < 0) { loc = -1; hic = -1; }
     int nbody = 0;
-    for (int cb = s_first; cb < S; cb += FCH) {
+    for (int cb = s_first; cb < Smax; cb += FCH) {
         const int lon = c.LO[min(cb + FCH + lane, S + LO_PAD - 1)], hin = c.HI[min(cb + FCH + lane, S + LO_PAD - 1)];
 #pragma unroll 1
-        for (int o = 0; o < FCH && cb + o < S; o += FB, nbody++) {
+        for (int o = 0; o < FCH && cb + o < Smax; o += FB, nbody++) {
             const int s0 = cb + o;
             int lov[FB], hiv[FB];
 #pragma unroll
@@ -576,15 +583,45 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, char* 
         gcmax[col] = __longlong_as_double((long long)*(unsigned long long*)(c.ring + (((unsigned)col * 8u) & c.ringmask)));
 }
 
-// MAXT = 512 lets the compiler keep the whole pipeline in registers; bands wider than 512 slots take the 1024-thread build
+// the barrier sequence of fill_body for a half without a sweep (no partner, or an inert job)
+__device__ __forceinline__ void fill_idle(const int Smax) {
+    __syncthreads();
+    __syncthreads();
+    const int s_first = 2 - FB;
+    for (int cb = s_first; cb < Smax; cb += FCH)
+        for (int o = 0; o < FCH && cb + o < Smax; o += FB)
+#pragma unroll
+            for (int k = 0; k < FB; k++) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __syncthreads();
+}
+
+// One workgroup = up to two sweeps (halves of P lanes each) over the SAME event, so that one 64 KB model table in LDS serves
+// both: the forward and backward fill of an alignment, or two candidate sequences against one event.  With P = 320 / 384 that is
+// 10 / 12 waves = 3 per SIMD: the four SIMDs carry equal instruction streams and one wave's exchange / barrier latency is covered
+// by the other two (a lone sweep's 5-6 waves leave one SIMD with two waves and the others waiting for it).
+// pairs[2 * blockIdx.x + h] = job * ndir + dir of half h, or -1.  PAIR = false: one sweep per workgroup (P > 384).
 // FASTDIV: tabulated reciprocals (the normal case) or IEEE divisions (some divisor of the AlignData is not a sane number)
-template <int MAXT, bool FASTDIV>
-__global__ __launch_bounds__(MAXT) void k_fill(BatchD b, int ndir, int rcols, int slowwords) {
+template <int MAXT, bool PAIR, bool FASTDIV>
+__global__ __launch_bounds__(MAXT) void k_fill(BatchD b, const int* __restrict__ pairs, int ndir, int P, int rcols, int slowwords, int halfbytes) {
     extern __shared__ double2 fill_smem[];
-    const int jd = blockIdx.x, job = jd / ndir, dir = jd % ndir;
-    const JobD& J = b.jobs[job];
-    if (J.out->inert) return;
-    if (dir == 0) fill_body<0, FASTDIV>(b, J, (char*)fill_smem, rcols, slowwords); else fill_body<1, FASTDIV>(b, J, (char*)fill_smem, rcols, slowwords);
+    char* smem = (char*)fill_smem;
+    const int hw = PAIR ? (int)threadIdx.x / P : 0;
+    const int slot = (int)threadIdx.x - hw * P;
+    const int jdA = pairs[2 * blockIdx.x], jdB = PAIR ? pairs[2 * blockIdx.x + 1] : -1;
+    const bool okA = jdA >= 0 && !b.jobs[jdA / ndir].out->inert, okB = jdB >= 0 && !b.jobs[jdB / ndir].out->inert;
+    if (!okA && !okB) return;
+    const int Smax = max(okA ? (int)b.jobs[jdA / ndir].S : 0, okB ? (int)b.jobs[jdB / ndir].S : 0);
+    {   // the event's model rows (64 bytes per 5-mer, laid out by the host): one copy for the workgroup
+        const double2* src = (const double2*)b.jobs[(okA ? jdA : jdB) / ndir].model8;
+        double2* dst = (double2*)smem;
+        for (int k = threadIdx.x; k < FILL_MODEL_BYTES / 16; k += blockDim.x) dst[k] = src[k];
+    }
+    const int jd = hw == 0 ? jdA : jdB;
+    if (!(hw == 0 ? okA : okB)) { fill_idle(Smax); return; }
+    const JobD& J = b.jobs[jd / ndir];
+    char* hsm = smem + FILL_MODEL_BYTES + hw * halfbytes;
+    if (jd % ndir == 0) fill_body<0, FASTDIV>(b, J, smem, hsm, slot, Smax, rcols, slowwords);
+    else fill_body<1, FASTDIV>(b, J, smem, hsm, slot, Smax, rcols, slowwords);
 }
 
 // prefix max over columns + (fwd) the first cell achieving the global max ; grid njobs*ndir, block 64
@@ -990,36 +1027,60 @@ int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS) {
     return PS_OK;
 }
 
-// LDS of one k_fill workgroup: the event's model rows (64 KB), two exchange buffers, the column-maxima ring, the slow-body bitmap
+// LDS of one k_fill workgroup: the event's model rows (64 KB) + per half two exchange buffers, the column-maxima ring, the slow-body bitmap
 static int fill_ring_cols(int P) { return P + 96 <= 512 ? 512 : (P + 96 <= 1024 ? 1024 : 2048); }
 static int fill_slow_words(int64_t maxS) { return (int)((maxS + 2 * FB) / FB / 32 + 2); }
-static size_t fill_lds_bytes(int P, int64_t maxS) {
-    return FILL_MODEL_BYTES + (size_t)2 * P * 24 + (size_t)fill_ring_cols(P) * 8 + (size_t)fill_slow_words(maxS) * 4;
+static int fill_half_bytes(int P, int64_t maxS) {
+    return (int)((((size_t)2 * P * 24 + (size_t)fill_ring_cols(P) * 8 + (size_t)fill_slow_words(maxS) * 4) + 63) / 64 * 64);
 }
 
-int launch_fill(Runtime* rt, const BatchD& b, int ndir, int64_t maxS, int P, int64_t ncols) {
+template <int MAXT, bool PAIR>
+static void fill_launch(Runtime* rt, const BatchD& b, const int* d_pairs, int nwg, int ndir, int P, int64_t maxS, size_t lds) {
+    const dim3 grid(nwg), block(PAIR ? 2 * P : P);
+    const int rc = fill_ring_cols(P), sw = fill_slow_words(maxS), hb = fill_half_bytes(P, maxS);
+    if (b.fastdiv) hipLaunchKernelGGL((k_fill<MAXT, PAIR, true>), grid, block, lds, rt->stream, b, d_pairs, ndir, P, rc, sw, hb);
+    else hipLaunchKernelGGL((k_fill<MAXT, PAIR, false>), grid, block, lds, rt->stream, b, d_pairs, ndir, P, rc, sw, hb);
+}
+
+int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int ndir, int64_t maxS, int P, int64_t ncols) {
     if (!b.njobs) return PS_OK;
     static bool attr_set = false;   // more than the default 64 KB of dynamic LDS needs the attribute (idempotent; racing threads set the same value)
     if (!attr_set) {
-        PS_HIP(hipFuncSetAttribute((const void*)k_fill<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PS_HIP(hipFuncSetAttribute((const void*)k_fill<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PS_HIP(hipFuncSetAttribute((const void*)k_fill<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PS_HIP(hipFuncSetAttribute((const void*)k_fill<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define PS_FILL_ATTR(...) PS_HIP(hipFuncSetAttribute((const void*)k_fill<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        PS_FILL_ATTR(768, true, true); PS_FILL_ATTR(768, true, false);
+        PS_FILL_ATTR(512, false, true); PS_FILL_ATTR(512, false, false);
+        PS_FILL_ATTR(1024, false, true); PS_FILL_ATTR(1024, false, false);
+#undef PS_FILL_ATTR
         attr_set = true;
     }
     PS_HIP(hipMemsetAsync(b.cmax, 0, ncols * sizeof(double), rt->stream));
-    const size_t lds = fill_lds_bytes(P, maxS);
+    // workgroups: two sweeps over the same event share one (model table in LDS): forward + backward of a job, or two
+    // forward-only jobs of one event (candidate sequences of FindMutations), longest with longest
+    const bool pair = 2 * P <= 768;
+    std::vector<int> pr;
+    if (pair && ndir == 2) {
+        for (int j = 0; j < b.njobs; j++) { pr.push_back(2 * j); pr.push_back(2 * j + 1); }
+    } else if (pair) {
+        std::map<const double*, std::vector<int>> by_event;
+        for (int j = 0; j < b.njobs; j++) by_event[jobs[j].model8].push_back(j);
+        for (auto& kv : by_event) {
+            std::vector<int>& v = kv.second;
+            std::sort(v.begin(), v.end(), [&](int x, int y) { return jobs[x].S != jobs[y].S ? jobs[x].S > jobs[y].S : x < y; });
+            for (size_t k = 0; k < v.size(); k += 2) { pr.push_back(v[k]); pr.push_back(k + 1 < v.size() ? v[k + 1] : -1); }
+        }
+    } else {
+        for (int jd = 0; jd < b.njobs * ndir; jd++) { pr.push_back(jd); pr.push_back(-1); }
+    }
+    const int nwg = (int)pr.size() / 2;
+    PS_TRY(rt->buf("fill_pairs").ensure(pr.size() * sizeof(int)));
+    int* d_pairs = rt->buf("fill_pairs").as<int>();
+    PS_TRY(rt->up(d_pairs, pr.data(), pr.size() * sizeof(int)));
+    const size_t lds = FILL_MODEL_BYTES + (size_t)(pair ? 2 : 1) * fill_half_bytes(P, maxS);
     if (lds > 160 * 1024) return fail(PS_ERR_UNSUPPORTED, "alignment too long for the fill kernel's LDS bitmap");
     prof_begin(rt);
-    const dim3 grid(b.njobs * ndir), block(P);
-    const int rc = fill_ring_cols(P), sw = fill_slow_words(maxS);
-    if (b.fastdiv) {
-        if (P <= 512) hipLaunchKernelGGL((k_fill<512, true>), grid, block, lds, rt->stream, b, ndir, rc, sw);
-        else hipLaunchKernelGGL((k_fill<1024, true>), grid, block, lds, rt->stream, b, ndir, rc, sw);
-    } else {
-        if (P <= 512) hipLaunchKernelGGL((k_fill<512, false>), grid, block, lds, rt->stream, b, ndir, rc, sw);
-        else hipLaunchKernelGGL((k_fill<1024, false>), grid, block, lds, rt->stream, b, ndir, rc, sw);
-    }
+    if (pair) fill_launch<768, true>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
+    else if (P <= 512) fill_launch<512, false>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
+    else fill_launch<1024, false>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
     PS_LAUNCH_CHECK();
     prof_end(rt, "fill", 0.0);
     hipLaunchKernelGGL(k_prefix, dim3(b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
