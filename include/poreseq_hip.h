@@ -131,6 +131,33 @@ int ps_rand_draw(int64_t n, double* out);
 int ps_viterbi_mutate(ps_align* a, int32_t nkeep, double skip_prob, double stay_prob,
                       double mut_min, double mut_max, int32_t verbose, ps_seqs** out);
 
+/* ---- lock-step batches over independent AlignData ----------------------------------------------------------------
+ * The reference refines one region per process (cmdline.py:182-195, split_fasta.py:50-133); regions are independent.
+ * One region keeps a few percent of an MI355X busy, so a driver that has several regions in hand runs the SAME call
+ * for all of them through these entry points: every phase (Smith-Waterman batch, banded fills, edit scoring, Viterbi)
+ * becomes one launch chain over all regions' events, from one host thread, on the library's own stream.  Results are
+ * those of the single-handle calls on each AlignData, bit for bit.  Arrays have n entries; handles must be distinct.
+ *
+ * ps_rng: the generator ViterbiMutate's stochastic back-traces draw from (rand() of cpp/Viterbi.cpp:108).  The
+ * reference's process-per-region model gives every region the stream of a fresh process, continued across the
+ * region's Viterbi calls; a lock-step driver therefore keeps one ps_rng per region (seed 1 = unseeded process). */
+typedef struct ps_rng ps_rng;
+int ps_rng_create(ps_rng** out, uint32_t seed);
+void ps_rng_destroy(ps_rng* r);
+/* vector<Sequence> from a CSR string pool (seed sequences for ps_batch_find_mutations). */
+int ps_seqs_create(ps_seqs** out, int64_t n, const int64_t* off, const char* pool);
+/* ScoreAlignments for n AlignData: scores[i] has n_events(i) entries, likes[i] is NULL or [sequence_length(i)]. */
+int ps_batch_score_alignments(int32_t n, ps_align* const* a, double* const* scores, double* const* likes);
+/* FindMutations: seeds[i] are the candidate sequences of AlignData i; out[i] receives a new ps_muts. */
+int ps_batch_find_mutations(int32_t n, ps_align* const* a, const ps_seqs* const* seeds, ps_muts** out);
+/* ScoreMutations: out[i] receives a new ps_muts with the scores of muts[i], same order. */
+int ps_batch_score_mutations(int32_t n, ps_align* const* a, const ps_muts* const* muts, ps_muts** out);
+/* MakeMutations: greedy application per AlignData; the re-scoring rounds of the recursion are batched. */
+int ps_batch_make_mutations(int32_t n, ps_align* const* a, const ps_muts* const* scored, int32_t* n_bases);
+/* ViterbiMutate: rng[i] may be NULL (the calling thread's generator, as ps_viterbi_mutate). */
+int ps_batch_viterbi_mutate(int32_t n, ps_align* const* a, ps_rng* const* rng, int32_t nkeep, double skip_prob,
+                            double stay_prob, double mut_min, double mut_max, ps_seqs** out);
+
 /* swfull (cpp/swlib.h:36, cpp/swlib.cpp:211-340).  inds1/inds2 need room for n1+n2 entries. */
 int ps_swfull(const char* seq1, int64_t n1, const char* seq2, int64_t n2, int32_t* score,
               double* accuracy, int32_t* inds1, int32_t* inds2, int64_t cap, int64_t* n_pairs);

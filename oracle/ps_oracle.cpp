@@ -815,6 +815,13 @@ int ps_muts_export(const ps_muts* m, int32_t* start, int64_t* oo, char* op, int6
     return PS_OK;
 }
 
+int ps_seqs_create(ps_seqs** out, int64_t n, const int64_t* off, const char* pool) {
+    if (!out || n < 0) return PS_ERR_BAD_ARG;
+    ps_seqs* s = new ps_seqs();
+    for (int64_t i = 0; i < n; i++) s->v.emplace_back(pool + off[i], pool + off[i + 1]);
+    *out = s;
+    return PS_OK;
+}
 void ps_seqs_destroy(ps_seqs* s) { delete s; }
 int64_t ps_seqs_count(const ps_seqs* s) { return s ? (int64_t)s->v.size() : 0; }
 int64_t ps_seqs_bytes(const ps_seqs* s) { int64_t t = 0; if (s) for (auto& x : s->v) t += x.size(); return t; }
@@ -915,3 +922,5 @@ int ps_prof_reset(void) { return PS_OK; }
 int ps_prof_get(const char*, double* ms, int64_t* n, double* b) { if (ms) *ms = 0; if (n) *n = 0; if (b) *b = 0; return PS_OK; }
 
 }  // extern "C"
+
+#include "ps_batch_loop.inc"   // lock-step batch entry points: loops over the calls above

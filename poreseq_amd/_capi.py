@@ -63,6 +63,15 @@ SYMBOLS = {
                                     C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
     "ps_srand": (C.c_int, [C.c_uint32]),
     "ps_rand_draw": (C.c_int, [C.c_int64, c_dp]),
+    "ps_rng_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
+    "ps_rng_destroy": (None, [C.c_void_p]),
+    "ps_seqs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, c_i64p, C.c_char_p]),
+    "ps_batch_score_alignments": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(c_dp), C.POINTER(c_dp)]),
+    "ps_batch_find_mutations": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "ps_batch_score_mutations": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "ps_batch_make_mutations": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_i32p]),
+    "ps_batch_viterbi_mutate": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
     "ps_swfull": (C.c_int, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, c_i32p, c_dp, c_i32p,
                             c_i32p, C.c_int64, c_i64p]),
     "ps_seq_to_states": (C.c_int, [C.c_char_p, C.c_int64, c_i32p, c_i64p]),
@@ -250,6 +259,71 @@ class CApi:
             return self.seqs_export(out)
         finally:
             self.lib.ps_seqs_destroy(out)
+
+    # ------------------------------------------------------------------ lock-step batches (several AlignData per call)
+    @staticmethod
+    def _harr(handles):
+        arr = (C.c_void_p * len(handles))()
+        for i, h in enumerate(handles):
+            arr[i] = h.value if isinstance(h, C.c_void_p) else h
+        return arr
+
+    def rng_create(self, seed=1):
+        h = C.c_void_p()
+        self.check(self.lib.ps_rng_create(C.byref(h), int(seed)))
+        return h
+
+    def rng_destroy(self, h):
+        self.lib.ps_rng_destroy(h)
+
+    def seqs_create(self, seqs):
+        bs = [s.encode("ascii") for s in seqs]
+        off = np.zeros(len(bs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(b) for b in bs])
+        h = C.c_void_p()
+        self.check(self.lib.ps_seqs_create(C.byref(h), len(bs), off.ctypes.data_as(c_i64p), b"".join(bs)))
+        return h
+
+    def seqs_destroy(self, h):
+        self.lib.ps_seqs_destroy(h)
+
+    def batch_score_alignments(self, handles, n_events):
+        n = len(handles)
+        scores = [np.zeros(max(int(e), 1), dtype=np.float64) for e in n_events]
+        sp = (c_dp * n)(*[_dp(a) for a in scores])
+        self.check(self.lib.ps_batch_score_alignments(n, self._harr(handles), sp, None))
+        return [a[:int(e)] for a, e in zip(scores, n_events)]
+
+    def batch_find_mutations(self, handles, seqs_handles):
+        n = len(handles)
+        out = (C.c_void_p * n)()
+        self.check(self.lib.ps_batch_find_mutations(n, self._harr(handles), self._harr(seqs_handles), out))
+        return [C.c_void_p(out[i]) for i in range(n)]
+
+    def batch_score_mutations(self, handles, muts_handles):
+        n = len(handles)
+        out = (C.c_void_p * n)()
+        self.check(self.lib.ps_batch_score_mutations(n, self._harr(handles), self._harr(muts_handles), out))
+        return [C.c_void_p(out[i]) for i in range(n)]
+
+    def batch_make_mutations(self, handles, muts_handles):
+        n = len(handles)
+        nb = np.zeros(max(n, 1), dtype=np.int32)
+        self.check(self.lib.ps_batch_make_mutations(n, self._harr(handles), self._harr(muts_handles), nb.ctypes.data_as(c_i32p)))
+        return [int(x) for x in nb[:n]]
+
+    def batch_viterbi_mutate(self, handles, rngs, nkeep, skip, stay, mmin, mmax):
+        n = len(handles)
+        out = (C.c_void_p * n)()
+        self.check(self.lib.ps_batch_viterbi_mutate(n, self._harr(handles), self._harr(rngs), nkeep, skip, stay, mmin, mmax, out))
+        res = []
+        for i in range(n):
+            h = C.c_void_p(out[i])
+            try:
+                res.append(self.seqs_export(h))
+            finally:
+                self.lib.ps_seqs_destroy(h)
+        return res
 
     def srand(self, seed):
         self.check(self.lib.ps_srand(int(seed)))

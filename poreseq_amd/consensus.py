@@ -61,6 +61,54 @@ def consensus_region(pa, params=None, reps=4, verbose=0, refseq=None, log=None):
     return (pa.sequence, acc)
 
 
+def consensus_regions(pas, params=None, reps=4, refseqs=None, logs=None):
+    """The consensus schedule of `consensus_region` for several independent regions in lock-step (poreseq_amd.batch):
+    every PSAlign call of the schedule is issued once for all regions that still take part in it, so each phase is one
+    launch chain on the GPU.  Returns [(sequence, accuracy)] in the order of `pas`; each entry equals what
+    `consensus_region(pa)` returns for that region run on its own from a fresh process.
+    `logs`, when given, is a list of lists receiving (call, nbases, sequence) per region after every call.
+    """
+    from .batch import RegionBatch
+    n = len(pas)
+    refseqs = [pa.sequence for pa in pas] if refseqs is None else list(refseqs)
+    out = [None] * n
+    todo = []
+    for i, pa in enumerate(pas):
+        if 'verbose' not in pa.params:
+            pa.params['verbose'] = 0
+        if len(pa.events) < 5:                      # Mutate.py:50-53
+            out[i] = (refseqs[i], 100)
+        else:
+            todo.append(i)
+    if todo:
+        def note(i, call, nb):
+            if logs is not None:
+                logs[i].append((call, nb, pas[i].sequence))
+        with RegionBatch(pas) as rb:
+            tot = rb.Mutate(todo, reps=reps)
+            for i in todo:
+                note(i, "Mutate:self", tot[i])
+            live = list(todo)
+            for _ in range(reps):
+                if not live:
+                    break
+                tot = rb.Mutate(live, seqs='viterbi')
+                for i in live:
+                    note(i, "Mutate:viterbi", tot[i])
+                nb = rb.Refine(live)
+                for i in live:
+                    note(i, "Refine", nb[i])
+                live = [i for i in live if nb[i] != 0]
+        api = pas[todo[0]]._native
+        for i in todo:
+            pa = pas[i]
+            p = pa.params if params is None else params
+            if 'end_trim' in p and len(pa.sequence) > 2 * p['end_trim']:
+                pa.sequence = pa.sequence[int(p['end_trim']):-int(p['end_trim'])]
+            out[i] = (pa.sequence, poreseqcpp.swalign(pa.sequence, refseqs[i], api)[0])
+    return out
+
+
 def variant_region(pa, muts, region_start=0, params=None, out=None):
     """Score `muts` (or every point edit when the list is empty) as Variant.py:66-95 does: starts are
     region-relative inside the call and absolute again in the returned / printed MutationScores."""

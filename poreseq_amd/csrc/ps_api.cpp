@@ -10,6 +10,7 @@ using namespace ps;
 struct ps_align { Align a; };
 struct ps_muts { std::vector<Mut> v; };
 struct ps_seqs { std::vector<std::string> v; };
+struct ps_rng { RandState* s = nullptr; ~ps_rng() { if (s) rand_state_free(s); } };
 
 #define NEED_RT()            \
     Runtime* rt = nullptr;   \
@@ -158,6 +159,107 @@ int ps_viterbi_mutate(ps_align* a, int32_t nkeep, double skip, double stay, doub
     *out = s.release();
     return PS_OK;
 }
+// ---- lock-step batches (include/poreseq_hip.h) ----
+int ps_rng_create(ps_rng** out, uint32_t seed) {
+    if (!out) return fail(PS_ERR_BAD_ARG, "ps_rng_create");
+    ps_rng* r = new ps_rng();
+    r->s = rand_state_new(seed);
+    *out = r;
+    return PS_OK;
+}
+void ps_rng_destroy(ps_rng* r) { delete r; }
+int ps_seqs_create(ps_seqs** out, int64_t n, const int64_t* off, const char* pool) {
+    if (!out || n < 0 || (n && (!off || !pool))) return fail(PS_ERR_BAD_ARG, "ps_seqs_create");
+    ps_seqs* s = new ps_seqs();
+    for (int64_t i = 0; i < n; i++) s->v.emplace_back(pool + off[i], pool + off[i + 1]);
+    *out = s;
+    return PS_OK;
+}
+static int batch_handles(int32_t n, ps_align* const* a, std::vector<Align*>* as) {
+    if (n < 0 || (n && !a)) return fail(PS_ERR_BAD_ARG, "batch: bad handle array");
+    for (int i = 0; i < n; i++) {
+        if (!a[i]) return fail(PS_ERR_BAD_ARG, "batch: null handle");
+        for (int j = 0; j < i; j++) if (a[j] == a[i]) return fail(PS_ERR_BAD_ARG, "batch: the same handle twice");
+        as->push_back(&a[i]->a);
+    }
+    return PS_OK;
+}
+int ps_batch_score_alignments(int32_t n, ps_align* const* a, double* const* scores, double* const* likes) {
+    std::vector<Align*> as;
+    PS_TRY(batch_handles(n, a, &as));
+    if (n && !scores) return fail(PS_ERR_BAD_ARG, "ps_batch_score_alignments");
+    NEED_RT();
+    std::vector<double*> sc(n), lk(n);
+    for (int i = 0; i < n; i++) {
+        if (!scores[i] && as[i]->E) return fail(PS_ERR_BAD_ARG, "ps_batch_score_alignments: null scores");
+        sc[i] = scores[i]; lk[i] = likes ? likes[i] : nullptr;
+    }
+    return score_alignments_multi(rt, as, sc, lk);
+}
+int ps_batch_find_mutations(int32_t n, ps_align* const* a, const ps_seqs* const* seeds, ps_muts** out) {
+    std::vector<Align*> as;
+    PS_TRY(batch_handles(n, a, &as));
+    if (n && (!seeds || !out)) return fail(PS_ERR_BAD_ARG, "ps_batch_find_mutations");
+    NEED_RT();
+    std::vector<std::unique_ptr<ps_muts>> m(n);
+    std::vector<const std::vector<std::string>*> sd(n);
+    std::vector<std::vector<Mut>*> o(n);
+    for (int i = 0; i < n; i++) {
+        if (!seeds[i]) return fail(PS_ERR_BAD_ARG, "ps_batch_find_mutations: null seeds");
+        m[i].reset(new ps_muts()); sd[i] = &seeds[i]->v; o[i] = &m[i]->v;
+    }
+    PS_TRY(find_mutations_multi(rt, as, sd, o));
+    for (int i = 0; i < n; i++) out[i] = m[i].release();
+    return PS_OK;
+}
+int ps_batch_score_mutations(int32_t n, ps_align* const* a, const ps_muts* const* muts, ps_muts** out) {
+    std::vector<Align*> as;
+    PS_TRY(batch_handles(n, a, &as));
+    if (n && (!muts || !out)) return fail(PS_ERR_BAD_ARG, "ps_batch_score_mutations");
+    NEED_RT();
+    std::vector<std::unique_ptr<ps_muts>> m(n);
+    std::vector<const std::vector<Mut>*> in(n);
+    std::vector<std::vector<Mut>*> o(n);
+    for (int i = 0; i < n; i++) {
+        if (!muts[i]) return fail(PS_ERR_BAD_ARG, "ps_batch_score_mutations: null list");
+        m[i].reset(new ps_muts()); in[i] = &muts[i]->v; o[i] = &m[i]->v;
+    }
+    PS_TRY(score_mutations_multi(rt, as, in, o));
+    for (int i = 0; i < n; i++) out[i] = m[i].release();
+    return PS_OK;
+}
+int ps_batch_make_mutations(int32_t n, ps_align* const* a, const ps_muts* const* scored, int32_t* n_bases) {
+    std::vector<Align*> as;
+    PS_TRY(batch_handles(n, a, &as));
+    if (n && (!scored || !n_bases)) return fail(PS_ERR_BAD_ARG, "ps_batch_make_mutations");
+    NEED_RT();
+    std::vector<std::vector<Mut>> in(n);
+    for (int i = 0; i < n; i++) {
+        if (!scored[i]) return fail(PS_ERR_BAD_ARG, "ps_batch_make_mutations: null list");
+        in[i] = scored[i]->v;
+    }
+    std::vector<int> nb;
+    PS_TRY(make_mutations_multi(rt, as, std::move(in), &nb));
+    for (int i = 0; i < n; i++) n_bases[i] = nb[i];
+    return PS_OK;
+}
+int ps_batch_viterbi_mutate(int32_t n, ps_align* const* a, ps_rng* const* rng, int32_t nkeep, double skip, double stay,
+                            double mmin, double mmax, ps_seqs** out) {
+    std::vector<Align*> as;
+    PS_TRY(batch_handles(n, a, &as));
+    if (n && !out) return fail(PS_ERR_BAD_ARG, "ps_batch_viterbi_mutate");
+    if (nkeep < 0) return fail(PS_ERR_BAD_ARG, "ps_batch_viterbi_mutate: nkeep");
+    for (Align* x : as) if (x->E == 0) return fail(PS_ERR_BAD_ARG, "ps_batch_viterbi_mutate: no events");
+    NEED_RT();
+    std::vector<std::unique_ptr<ps_seqs>> s(n);
+    std::vector<RandState*> rs(n, nullptr);
+    std::vector<std::vector<std::string>*> o(n);
+    for (int i = 0; i < n; i++) { s[i].reset(new ps_seqs()); o[i] = &s[i]->v; rs[i] = (rng && rng[i]) ? rng[i]->s : nullptr; }
+    PS_TRY(viterbi_mutate_multi(rt, as, rs, nkeep, skip, stay, mmin, mmax, o));
+    for (int i = 0; i < n; i++) out[i] = s[i].release();
+    return PS_OK;
+}
+
 int ps_swfull(const char* s1, int64_t n1, const char* s2, int64_t n2, int32_t* score, double* acc,
               int32_t* i1, int32_t* i2, int64_t cap, int64_t* np) {
     if (!s1 || !s2 || n1 < 0 || n2 < 0 || !np) return fail(PS_ERR_BAD_ARG, "ps_swfull");

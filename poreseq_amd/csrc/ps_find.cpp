@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 
 #include "ps_host.h"
@@ -13,11 +14,14 @@
 
 namespace ps {
 
-// cap on the DP-matrix bytes of one seed batch (PORESEQ_MAX_BATCH_GB, default 48): lower it when several host
-// threads share one GPU
+// cap on the DP-matrix bytes of one batch of candidate-sequence alignments: PORESEQ_MAX_BATCH_GB when set (read at
+// every call), otherwise half of the device memory that is free right now divided by the number of host threads that
+// currently own a runtime (each keeps its own grow-only pools)
 static double max_batch_bytes() {
-    static const double v = [] { const char* e = getenv("PORESEQ_MAX_BATCH_GB"); const double g = e ? atof(e) : 48.0; return (g > 0 ? g : 48.0) * 1e9; }();
-    return v;
+    if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || !fr) return 48e9;
+    return std::max(2e9, 0.5 * (double)fr / std::max(1, live_runtimes()));
 }
 
 static void fillinds(SwResult& al) {  // cpp/swlib.cpp:342-365
@@ -31,140 +35,12 @@ static void fillinds(SwResult& al) {  // cpp/swlib.cpp:342-365
 
 static int argmax(const std::vector<double>& v) { return (int)(std::max_element(v.begin(), v.end()) - v.begin()); }
 
-int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds, std::vector<Mut>* out) {
-    out->clear();
+// the tail of FindMutations for one AlignData (host only): likelihood differences along the pairwise alignments ->
+// clamped CUSUM -> greedy extraction of candidate edits (cpp/FindMutations.cpp:51-183)
+static int extract_edits(Align* a, const std::vector<std::string>& seeds, std::vector<SwResult>& als, const std::vector<double>& base,
+                         std::vector<Mut>* out) {
     const size_t L = a->bases.size();
-    // re-align to the current sequence, keeping per-base cumulative likelihoods (cpp/FindMutations.cpp:28-29)
-    std::vector<double> base(std::max<size_t>(L, 4) + 1, 0.0), sc(std::max(a->E, 1));
-    Tick tk("find_mutations");
     const int S = (int)seeds.size();
-    // Smith-Waterman of the current sequence against every seed (MapAlignments, cpp/EventUtil.cpp:16):
-    // independent of the re-alignment below, so it runs concurrently on the second stream
-    std::vector<std::pair<const std::string*, const std::string*>> pairs;
-    for (const std::string& s : seeds) pairs.push_back({&a->bases, &s});
-    SwJob swjob;
-    PS_TRY(sw_launch(rt, pairs, &swjob));
-    tk.lap("sw enqueue");
-    const int rc_base = score_alignments(rt, a, sc.data(), base.data());
-    tk.lap("base realign");
-    std::vector<SwResult> als;
-    PS_TRY(sw_finish(rt, &swjob, &als));   // always drain the second stream, even on failure above
-    PS_TRY(rc_base);
-    if (!S) return PS_OK;
-    for (SwResult& al : als) fillinds(al);
-    tk.lap("smith-waterman");
-    // seeds whose likelihood vector is not cached yet get (seed x event) alignment jobs
-    std::vector<int> need;
-    {
-        std::map<std::string, int> seen;
-        for (int k = 0; k < S; k++) {
-            if (!a->seqlikes[seeds[k]].empty()) continue;
-            if (seen.count(seeds[k])) continue;
-            seen[seeds[k]] = k;
-            need.push_back(k);
-        }
-    }
-    if (!need.empty() && a->E) {
-        PS_TRY(a->refs_to_host(rt));
-        std::vector<std::vector<int>> sstates(need.size());
-        for (size_t q = 0; q < need.size(); q++) sstates[q] = states_of(seeds[need[q]]);
-        // chunk the seeds so the DP matrices of one batch stay below ~48 GB
-        const int W = a->par.realign_width;
-        const int P = std::max(64, ((W + 1 + 63) / 64) * 64);  // typical anti-diagonal footprint is about half the band
-        size_t q0 = 0;
-        while (q0 < need.size()) {
-            size_t q1 = q0;
-            double bytes = 0;
-            while (q1 < need.size()) {
-                double add = 0;
-                for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + sstates[q1].size() + 1) * P * 26.0;
-                if (q1 > q0 && bytes + add > max_batch_bytes()) break;
-                bytes += add; q1++;
-            }
-            const size_t ns = q1 - q0;
-            // remapped ref_align of every (seed, event) job, cpp/EventUtil.cpp:22-51
-            const size_t nref = (size_t)ns * a->ntot;
-            const size_t stage_mark = rt->stage.mark();
-            double* h_ra = (double*)rt->stage.alloc(std::max<size_t>(nref, 1) * sizeof(double));   // pinned: plain enqueue below
-            if (!h_ra) return fail(PS_ERR_NOMEM, "hipHostMalloc (staging arena)");
-            auto remap_seed = [&](size_t q) {
-                const SwResult& al = als[need[q]];
-                double* dst = h_ra + (q - q0) * a->ntot;
-                for (int64_t t = 0; t < a->ntot; t++) {
-                    const int ra = (int)a->h_ra[t];
-                    double v = 0.0;
-                    if (!al.a.empty() && !(ra < al.a.front() || ra > al.a.back())) {
-                        const size_t k = std::lower_bound(al.a.begin(), al.a.end(), ra) - al.a.begin();
-                        v = k < al.b.size() ? (double)al.b[k] : 0.0;
-                    }
-                    dst[t] = v;
-                }
-            };
-            {   // one host thread per seed (pure index arithmetic on disjoint outputs)
-                std::vector<std::thread> th;
-                for (size_t q = q0 + 1; q < q1; q++) th.emplace_back(remap_seed, q);
-                remap_seed(q0);
-                for (std::thread& x : th) x.join();
-            }
-            tk.lap("remap (host)");
-            DBuf& rb = rt->buf("seed_refs");
-            PS_TRY(rb.ensure((size_t)3 * ns * std::max<int64_t>(a->ntot, 1) * sizeof(double)));
-            double* d_ra = rb.as<double>();
-            double* d_rl = d_ra + ns * a->ntot;
-            double* d_ri = d_rl + ns * a->ntot;
-            if (nref) PS_HIP(hipMemcpyAsync(d_ra, h_ra, nref * sizeof(double), hipMemcpyHostToDevice, rt->stream));
-            PS_HIP(hipMemsetAsync(d_rl, 0, ns * a->ntot * sizeof(double), rt->stream));
-            std::vector<JobSpec> specs;
-            for (size_t q = q0; q < q1; q++)
-                for (int e = 0; e < a->E; e++) {
-                    JobSpec s;
-                    s.a = a; s.ev = e; s.states = &sstates[q];
-                    const size_t o = (q - q0) * a->ntot + a->off[e];
-                    s.ra = d_ra + o; s.rl = d_rl + o; s.ri = d_ri + o;
-                    specs.push_back(s);
-                }
-            DBuf& ob = rt->buf("seed_out");
-            PS_TRY(ob.ensure(specs.size() * sizeof(JobOut)));   // (before the out pointers are taken: ensure() may move the buffer)
-            PS_HIP(hipMemsetAsync(ob.p, 0, specs.size() * sizeof(JobOut), rt->stream));
-            for (size_t k = 0; k < specs.size(); k++) specs[k].out = ob.as<JobOut>() + k;
-            Batch b;
-            PS_TRY(b.build(rt, specs, 1, 0));
-            PS_TRY(launch_updaterefs(rt, b.d));  // MapAlignments ends with updaterefs (cpp/EventUtil.cpp:51)
-            tk.lap("seed batch build");
-            PS_TRY(realign(rt, b));
-            PS_HIP(hipStreamSynchronize(rt->stream));
-            tk.lap("seed realign");
-            double *r_ra = nullptr, *r_rl = nullptr;
-            PS_TRY(rt->down(&r_ra, d_ra, nref));
-            PS_TRY(rt->down(&r_rl, d_rl, nref));
-            PS_HIP(hipStreamSynchronize(rt->stream));
-            tk.lap("seed D2H");
-            std::vector<std::vector<double>> lks(ns);
-            auto likes_seed = [&](size_t q) {
-                const std::string& sd = seeds[need[q]];
-                std::vector<double>& lk = lks[q - q0];
-                lk.assign(std::max<size_t>(sd.size(), 4) + 1, 0.0);
-                for (int e = 0; e < a->E; e++) {
-                    const size_t o = (q - q0) * a->ntot + a->off[e];
-                    accumulate_likes(r_ra + o, r_rl + o, a->n[e], (int)sstates[q].size(), lk.data());
-                }
-                lk.resize(sd.size());
-            };
-            {
-                std::vector<std::thread> th;
-                for (size_t q = q0 + 1; q < q1; q++) th.emplace_back(likes_seed, q);
-                likes_seed(q0);
-                for (std::thread& x : th) x.join();
-            }
-            for (size_t q = q0; q < q1; q++) a->seqlikes[seeds[need[q]]] = std::move(lks[q - q0]);
-            rt->stage.release(stage_mark);   // the stream is idle: this batch's staging memory can be reused
-            q0 = q1;
-        }
-    } else if (!need.empty()) {
-        for (int k : need) a->seqlikes[seeds[k]] = std::vector<double>(seeds[k].size(), 0.0);
-    }
-    tk.lap("seed likes");
-    // per seed: likelihood differences along the pairwise alignment -> clamped CUSUM (cpp/FindMutations.cpp:51-98)
     std::vector<std::vector<double>> dl(S);
     for (int k = 0; k < S; k++) {
         SwResult& al = als[k];
@@ -189,10 +65,9 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
             if (std::fabs(x[q] - y[q]) < 1e-5) cs[q] = 0;
         }
     }
-    tk.lap("cusum");
-    // greedy extraction of candidate edits (cpp/FindMutations.cpp:111-183).  The reference rescans every
-    // seed's vector for its maximum on each round; here per-seed block maxima (128 entries per block)
-    // are kept current instead — same first-maximum semantics (std::max_element), same output.
+    // greedy extraction (cpp/FindMutations.cpp:111-183).  The reference rescans every seed's vector for its maximum on
+    // each round; here per-seed block maxima (128 entries per block) are kept current instead — same first-maximum
+    // semantics (std::max_element), same output.
     const size_t BLK = 128;
     std::vector<std::vector<double>> bmax(S);
     auto block_refresh = [&](int k, size_t blk) {
@@ -237,8 +112,7 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
         const int s1 = als[w].a[i0], s2 = als[w].b[i0], e1 = als[w].a[ind], e2 = als[w].b[ind];
         Mut m;
         m.start = s1;
-        if ((size_t)s1 > a->bases.size() || (size_t)s2 > seeds[w].size())
-            return fail(PS_ERR_BAD_ARG, "FindMutations: alignment index outside the sequence");
+        if ((size_t)s1 > a->bases.size() || (size_t)s2 > seeds[w].size()) return PS_ERR_BAD_ARG;
         m.orig = a->bases.substr(s1, (size_t)(e1 - s1));
         m.mut = seeds[w].substr(s2, (size_t)(e2 - s2));
         while (!m.orig.empty() && !m.mut.empty() && m.orig.front() == m.mut.front()) {
@@ -251,8 +125,169 @@ int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds,
         topi[w] = seed_argmax(w);
         top[w] = v[topi[w]];
     }
+    return PS_OK;
+}
+
+// FindMutations (cpp/FindMutations.cpp:24-186) for several AlignData in lock-step: one Smith-Waterman batch for all
+// (sequence, seed) pairs, one base realign over all events, the candidate-sequence alignments of all regions in as few
+// launch chains as device memory allows, then the host-side extraction per AlignData on host threads
+int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<std::string>*>& seeds,
+                         const std::vector<std::vector<Mut>*>& outs) {
+    Tick tk("find_mutations");
+    const int R = (int)as.size();
+    for (int r = 0; r < R; r++) outs[r]->clear();
+    // Smith-Waterman of every current sequence against each of its seeds (MapAlignments, cpp/EventUtil.cpp:16): independent of
+    // the re-alignment below, so it runs concurrently on the second stream
+    std::vector<std::pair<const std::string*, const std::string*>> pairs;
+    std::vector<int> pair0(R + 1, 0);
+    for (int r = 0; r < R; r++) {
+        pair0[r] = (int)pairs.size();
+        for (const std::string& s : *seeds[r]) pairs.push_back({&as[r]->bases, &s});
+    }
+    pair0[R] = (int)pairs.size();
+    SwJob swjob;
+    PS_TRY(sw_launch(rt, pairs, &swjob));
+    tk.lap("sw enqueue");
+    // re-align to the current sequences, keeping per-base cumulative likelihoods (cpp/FindMutations.cpp:28-29)
+    std::vector<std::vector<double>> base(R), sc(R);
+    std::vector<double*> scp(R), lkp(R);
+    for (int r = 0; r < R; r++) {
+        base[r].assign(std::max<size_t>(as[r]->bases.size(), 4) + 1, 0.0);
+        sc[r].assign(std::max(as[r]->E, 1), 0.0);
+        scp[r] = sc[r].data(); lkp[r] = base[r].data();
+    }
+    const int rc_base = score_alignments_multi(rt, as, scp, lkp);
+    tk.lap("base realign");
+    std::vector<SwResult> als_all;
+    PS_TRY(sw_finish(rt, &swjob, &als_all));   // always drain the second stream, even on failure above
+    PS_TRY(rc_base);
+    if (pairs.empty()) return PS_OK;
+    par_for((int)als_all.size(), [&](int k) { fillinds(als_all[k]); });
+    tk.lap("smith-waterman");
+    // (region, seed) pairs whose likelihood vector is not cached yet get (seed x event) alignment jobs
+    struct Need { int r, k; std::vector<int> states; };
+    std::vector<Need> need;
+    for (int r = 0; r < R; r++) {
+        Align* a = as[r];
+        const std::vector<std::string>& sd = *seeds[r];
+        std::map<std::string, int> seen;
+        for (int k = 0; k < (int)sd.size(); k++) {
+            if (!a->seqlikes[sd[k]].empty()) continue;
+            if (seen.count(sd[k])) continue;
+            seen[sd[k]] = k;
+            if (a->E) need.push_back({r, k, {}});
+            else a->seqlikes[sd[k]] = std::vector<double>(sd[k].size(), 0.0);
+        }
+    }
+    if (!need.empty()) {
+        {   // host mirrors of ref_align for the remap: one synchronisation for all
+            for (int r = 0; r < R; r++) PS_TRY(as[r]->refs_to_host_async(rt));
+            PS_HIP(hipStreamSynchronize(rt->stream));
+            for (int r = 0; r < R; r++) as[r]->refs_finish();
+        }
+        par_for((int)need.size(), [&](int q) { need[q].states = states_of((*seeds[need[q].r])[need[q].k]); });
+        const double cap = max_batch_bytes();
+        size_t q0 = 0;
+        while (q0 < need.size()) {
+            // chunk: as many (region, seed) pairs as the matrix budget holds (typical anti-diagonal footprint ~ half the band)
+            size_t q1 = q0;
+            double bytes = 0;
+            size_t nref = 0;
+            while (q1 < need.size()) {
+                const Align* a = as[need[q1].r];
+                const int P = std::max(64, ((a->par.realign_width + 10 + 63) / 64) * 64);
+                double add = 0;
+                for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + need[q1].states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0;
+                if (q1 > q0 && bytes + add > cap) break;
+                bytes += add; nref += (size_t)a->ntot; q1++;
+            }
+            const size_t stage_mark = rt->stage.mark();
+            double* h_ra = (double*)rt->stage.alloc(std::max<size_t>(nref, 1) * sizeof(double));   // pinned: plain enqueue below
+            if (!h_ra) return fail(PS_ERR_NOMEM, "hipHostMalloc (staging arena)");
+            std::vector<size_t> roff(q1 - q0 + 1, 0);
+            for (size_t q = q0; q < q1; q++) roff[q - q0 + 1] = roff[q - q0] + (size_t)as[need[q].r]->ntot;
+            // remapped ref_align of every (seed, event) job, cpp/EventUtil.cpp:22-51
+            par_for((int)(q1 - q0), [&](int qq) {
+                const Need& nd = need[q0 + qq];
+                const Align* a = as[nd.r];
+                const SwResult& al = als_all[pair0[nd.r] + nd.k];
+                double* dst = h_ra + roff[qq];
+                for (int64_t t = 0; t < a->ntot; t++) {
+                    const int ra = (int)a->h_ra[t];
+                    double v = 0.0;
+                    if (!al.a.empty() && !(ra < al.a.front() || ra > al.a.back())) {
+                        const size_t k = std::lower_bound(al.a.begin(), al.a.end(), ra) - al.a.begin();
+                        v = k < al.b.size() ? (double)al.b[k] : 0.0;
+                    }
+                    dst[t] = v;
+                }
+            });
+            tk.lap("remap (host)");
+            DBuf& rb = rt->buf("seed_refs");
+            PS_TRY(rb.ensure((size_t)3 * std::max<size_t>(nref, 1) * sizeof(double)));
+            double* d_ra = rb.as<double>();
+            double* d_rl = d_ra + nref;
+            double* d_ri = d_rl + nref;
+            if (nref) PS_HIP(hipMemcpyAsync(d_ra, h_ra, nref * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+            PS_HIP(hipMemsetAsync(d_rl, 0, std::max<size_t>(nref, 1) * sizeof(double), rt->stream));
+            size_t njobs = 0;
+            for (size_t q = q0; q < q1; q++) njobs += as[need[q].r]->E;
+            DBuf& ob = rt->buf("seed_out");
+            PS_TRY(ob.ensure(njobs * sizeof(JobOut)));   // (before the out pointers are taken: ensure() may move the buffer)
+            PS_HIP(hipMemsetAsync(ob.p, 0, njobs * sizeof(JobOut), rt->stream));
+            std::vector<JobSpec> specs;
+            for (size_t q = q0; q < q1; q++) {
+                Align* a = as[need[q].r];
+                for (int e = 0; e < a->E; e++) {
+                    JobSpec s;
+                    s.a = a; s.ev = e; s.states = &need[q].states;
+                    const size_t o = roff[q - q0] + a->off[e];
+                    s.ra = d_ra + o; s.rl = d_rl + o; s.ri = d_ri + o;
+                    s.out = ob.as<JobOut>() + specs.size();
+                    specs.push_back(s);
+                }
+            }
+            Batch b;
+            PS_TRY(b.build(rt, specs, 1, 0));
+            PS_TRY(launch_updaterefs(rt, b.d));  // MapAlignments ends with updaterefs (cpp/EventUtil.cpp:51)
+            tk.lap("seed batch build");
+            PS_TRY(realign(rt, b));
+            double *r_ra = nullptr, *r_rl = nullptr;
+            PS_TRY(rt->down(&r_ra, d_ra, nref));
+            PS_TRY(rt->down(&r_rl, d_rl, nref));
+            PS_HIP(hipStreamSynchronize(rt->stream));
+            tk.lap("seed realign + D2H");
+            std::vector<std::vector<double>> lks(q1 - q0);
+            par_for((int)(q1 - q0), [&](int qq) {
+                const Need& nd = need[q0 + qq];
+                const Align* a = as[nd.r];
+                const std::string& sd = (*seeds[nd.r])[nd.k];
+                std::vector<double>& lk = lks[qq];
+                lk.assign(std::max<size_t>(sd.size(), 4) + 1, 0.0);
+                for (int e = 0; e < a->E; e++) {
+                    const size_t o = roff[qq] + a->off[e];
+                    accumulate_likes(r_ra + o, r_rl + o, a->n[e], (int)nd.states.size(), lk.data());
+                }
+                lk.resize(sd.size());
+            });
+            for (size_t q = q0; q < q1; q++) as[need[q].r]->seqlikes[(*seeds[need[q].r])[need[q].k]] = std::move(lks[q - q0]);
+            rt->stage.release(stage_mark);   // the stream is idle: this batch's staging memory can be reused
+            q0 = q1;
+        }
+    }
+    tk.lap("seed likes");
+    std::vector<int> rcs(R, PS_OK);
+    par_for(R, [&](int r) {
+        std::vector<SwResult> als(als_all.begin() + pair0[r], als_all.begin() + pair0[r + 1]);
+        rcs[r] = extract_edits(as[r], *seeds[r], als, base[r], outs[r]);
+    });
+    for (int r = 0; r < R; r++) if (rcs[r] != PS_OK) return fail(rcs[r], "FindMutations: alignment index outside the sequence");
     tk.lap("extract");
     return PS_OK;
+}
+
+int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds, std::vector<Mut>* out) {
+    return find_mutations_multi(rt, {a}, {&seeds}, {out});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -279,41 +314,40 @@ static std::string path_to_bases(const std::vector<int>& st) {
     return s;
 }
 
-// rand() of a fresh process, per host thread (include/poreseq_hip.h, ps_srand): glibc's reentrant random_r() on
-// a 128-byte TYPE_3 state is the generator behind rand() minus the process-wide lock.
-namespace {
+// rand() of a fresh process, per region: glibc's reentrant random_r() on a 128-byte TYPE_3 state is the generator behind
+// rand() minus the process-wide lock.  A state is either the calling thread's (ps_srand / ps_rand_draw, the single-handle
+// ABI) or an explicit ps_rng object that a lock-step driver keeps per region (include/poreseq_hip.h).
 struct RandState {
     random_data rd;
     char st[128];
     bool init = false;
 };
-thread_local RandState t_rand;
-}  // namespace
-void rand_seed(unsigned seed) {
-    memset(&t_rand.rd, 0, sizeof(t_rand.rd));
-    initstate_r(seed, t_rand.st, sizeof(t_rand.st), &t_rand.rd);
-    t_rand.init = true;
+namespace { thread_local RandState t_rand; }
+static void rs_seed(RandState* r, unsigned seed) {
+    memset(&r->rd, 0, sizeof(r->rd));
+    initstate_r(seed, r->st, sizeof(r->st), &r->rd);
+    r->init = true;
 }
-int rand_next() {
-    if (!t_rand.init) rand_seed(1);
-    int32_t r = 0;
-    random_r(&t_rand.rd, &r);
-    return (int)r;
+static int rs_next(RandState* r) {
+    if (!r->init) rs_seed(r, 1);
+    int32_t v = 0;
+    random_r(&r->rd, &v);
+    return (int)v;
 }
+void rand_seed(unsigned seed) { rs_seed(&t_rand, seed); }
+int rand_next() { return rs_next(&t_rand); }
+RandState* rand_state_new(unsigned seed) { RandState* r = new RandState(); rs_seed(r, seed); return r; }
+void rand_state_free(RandState* r) { delete r; }
+void rand_state_seed(RandState* r, unsigned seed) { rs_seed(r, seed); }
+int rand_state_next(RandState* r) { return rs_next(r ? r : &t_rand); }
 
-int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, double mmin, double mmax,
-                   std::vector<std::string>* out) {
-    out->clear();
-    Tick tk("viterbi_mutate");
+namespace {
+// host part of ViterbiMutate for one AlignData: which reference positions are kept and the mean level per (position, event)
+struct VitGather { std::vector<double> obsin; int T = 0; };
+}  // namespace
+
+static void vit_gather(const Align* a, const double* h_ri, const JobOut* info, VitGather* g) {
     const int E = a->E;
-    // host mirrors of ref_align / ref_index / refstart / refend
-    PS_TRY(a->refs_to_host(rt));
-    double* h_ri = nullptr;
-    JobOut* info = nullptr;
-    PS_TRY(rt->down(&h_ri, a->d_ri, (size_t)a->ntot));
-    PS_TRY(rt->down(&info, a->d_out, (size_t)E));
-    PS_HIP(hipStreamSynchronize(rt->stream));
-    tk.lap("refs D2H");
     // first level whose ref_index equals an integer position (std::find in getrefstates, cpp/EventData.h:192),
     // as a flat table per event indexed by position (positions outside [0, maxpos] never match)
     // (extrapolated ref_index values past refend can be integers too and do take part, so the table
@@ -340,12 +374,11 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
             }
         }
     }
-    tk.lap("first-index maps");
     auto rstart = [&](int e) { return info[e].has_index ? info[e].refstart : -1; };
     auto rend = [&](int e) { return info[e].has_index ? info[e].refend : -1; };
     int refind = rstart(0);
     for (int e = 0; e < E; e++) refind = std::min(refind, rstart(e));
-    std::vector<double> obsin;
+    std::vector<double>& obsin = g->obsin;
     int T = 0;
     while (true) {
         int nl = 0, nal = 0;
@@ -357,13 +390,12 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
             const double* mean = a->h_mean.data() + a->off[e];
             const double* stdv = a->h_stdv.data() + a->off[e];
             int t = first[e][refind], cnt = 1;
-            double lvl = mean[t], sd = stdv[t];
             // getrefstates keeps following levels while ref_align <= refind, using those > 0 (cpp/EventData.h:197-201)
             double lsum = 0, ssum = 0;
             lsum += mean[t]; ssum += stdv[t];
             for (t++; t < a->n[e] && ra[t] <= refind; t++)
                 if (ra[t] > 0) { lsum += mean[t]; ssum += stdv[t]; cnt++; }
-            lvl = lsum / cnt; sd = ssum / cnt;
+            const double lvl = lsum / cnt, sd = ssum / cnt;
             nl++;
             double* o = obsin.data() + at + (size_t)e * 4;
             o[0] = lvl; o[1] = sd; o[2] = std::log(sd); o[3] = 1.0;
@@ -378,16 +410,52 @@ int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, d
         T++;
         refind++;
     }
+    g->T = T;
+}
+
+// uniform deviates in the reference's call order: for each kept path, one per back-step (cpp/Viterbi.cpp:108)
+static void vit_draw(void* rng, double* rnd, size_t n) {
+    RandState* r = (RandState*)rng;
+    for (size_t k = 0; k < n; k++) rnd[k] = rand_state_next(r) / (double(RAND_MAX) + 1);
+}
+
+// ViterbiMutate (cpp/Viterbi.cpp:239-426) for several AlignData in lock-step; rngs[r] = the region's generator (nullptr: the
+// calling thread's)
+int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<RandState*>& rngs, int nkeep, double skip, double stay,
+                         double mmin, double mmax, const std::vector<std::vector<std::string>*>& outs) {
+    Tick tk("viterbi_mutate");
+    const int R = (int)as.size();
+    for (int r = 0; r < R; r++) outs[r]->clear();
+    // host mirrors of ref_align / ref_index / refstart / refend
+    std::vector<double*> h_ri(R, nullptr);
+    std::vector<JobOut*> info(R, nullptr);
+    for (int r = 0; r < R; r++) {
+        PS_TRY(as[r]->refs_to_host_async(rt));
+        PS_TRY(rt->down(&h_ri[r], as[r]->d_ri, (size_t)as[r]->ntot));
+        PS_TRY(rt->down(&info[r], as[r]->d_out, (size_t)as[r]->E));
+    }
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    for (int r = 0; r < R; r++) as[r]->refs_finish();
+    tk.lap("refs D2H");
+    std::vector<VitGather> gath(R);
+    par_for(R, [&](int r) { vit_gather(as[r], h_ri[r], info[r], &gath[r]); });
     tk.lap("gather levels");
-    if (T == 0) return PS_OK;
-    // uniform deviates in the reference's call order: for each kept path, one per back-step (cpp/Viterbi.cpp:108)
-    auto draw = [](double* rnd, size_t n) { for (size_t k = 0; k < n; k++) rnd[k] = rand_next() / (double(RAND_MAX) + 1); };
-    std::vector<std::vector<int>> paths;
-    PS_TRY(viterbi_device(rt, E, T, obsin.data(), a->d_model, nkeep, skip, stay, mmin, mmax, draw, &paths));
+    std::vector<VitRegionH> regs(R);
+    for (int r = 0; r < R; r++) {
+        regs[r].E = as[r]->E; regs[r].T = gath[r].T; regs[r].obsin = gath[r].obsin.data(); regs[r].d_model = as[r]->d_model;
+        regs[r].rng = rngs[r]; regs[r].draw = vit_draw;
+    }
+    std::vector<std::vector<std::vector<int>>> paths;
+    PS_TRY(viterbi_device_multi(rt, regs, nkeep, skip, stay, mmin, mmax, &paths));
     tk.lap("device");
-    for (auto& p : paths) out->push_back(path_to_bases(p));
+    par_for(R, [&](int r) { for (auto& p : paths[r]) outs[r]->push_back(path_to_bases(p)); });
     tk.lap("paths to bases");
     return PS_OK;
+}
+
+int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, double mmin, double mmax,
+                   std::vector<std::string>* out) {
+    return viterbi_mutate_multi(rt, {a}, {nullptr}, nkeep, skip, stay, mmin, mmax, {out});
 }
 
 }  // namespace ps

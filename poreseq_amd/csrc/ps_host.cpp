@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <functional>
 #include <numeric>
 #include <mutex>
 #include <thread>
@@ -116,10 +118,13 @@ std::mutex g_rt_mu;
 std::vector<RtSlot*> g_rt_free;
 struct RtHolder {
     RtSlot* s = nullptr;
-    ~RtHolder() { if (s) { std::lock_guard<std::mutex> lk(g_rt_mu); g_rt_free.push_back(s); } }
+    ~RtHolder();
 };
 thread_local RtHolder t_rt;
+std::atomic<int> g_rt_live(0);
 }  // namespace
+int live_runtimes() { return g_rt_live.load(); }
+RtHolder::~RtHolder() { if (s) { std::lock_guard<std::mutex> lk(g_rt_mu); g_rt_free.push_back(s); g_rt_live--; } }
 
 int second_stream(Runtime* rt, hipStream_t* out) {
     if (getenv("PORESEQ_ONE_STREAM")) { *out = rt->stream; return PS_OK; }
@@ -133,6 +138,7 @@ int runtime(Runtime** out) {
         std::lock_guard<std::mutex> lk(g_rt_mu);
         if (!g_rt_free.empty()) { t_rt.s = g_rt_free.back(); g_rt_free.pop_back(); }
         else t_rt.s = new RtSlot();
+        g_rt_live++;
         if (t_rt.s->state == 1) (void)hipSetDevice(t_rt.s->R.device);   // the current device is per-thread state
     }
     Runtime& R = t_rt.s->R;
@@ -433,15 +439,23 @@ int Align::base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra) {
     return b->build(rt, specs, ndir, lb_extra);
 }
 
-int Align::refs_to_host(Runtime* rt) {
+// device -> host mirror of ref_align / ref_like in two halves, so that several AlignData can share one synchronisation
+int Align::refs_to_host_async(Runtime* rt) {
+    pend_ra = nullptr; pend_rl = nullptr;
     if (host_refs_valid || !ntot) { host_refs_valid = true; return PS_OK; }
-    double *pa = nullptr, *pl = nullptr;
-    PS_TRY(rt->down(&pa, d_ra, (size_t)ntot));
-    PS_TRY(rt->down(&pl, d_rl, (size_t)ntot));
-    PS_HIP(hipStreamSynchronize(rt->stream));
-    memcpy(h_ra.data(), pa, ntot * 8);
-    memcpy(h_rl.data(), pl, ntot * 8);
+    PS_TRY(rt->down(&pend_ra, d_ra, (size_t)ntot));
+    PS_TRY(rt->down(&pend_rl, d_rl, (size_t)ntot));
+    return PS_OK;
+}
+void Align::refs_finish() {   // after the stream has been synchronised
+    if (pend_ra) { memcpy(h_ra.data(), pend_ra, ntot * 8); memcpy(h_rl.data(), pend_rl, ntot * 8); }
+    pend_ra = nullptr; pend_rl = nullptr;
     host_refs_valid = true;
+}
+int Align::refs_to_host(Runtime* rt) {
+    PS_TRY(refs_to_host_async(rt));
+    if (pend_ra) PS_HIP(hipStreamSynchronize(rt->stream));
+    refs_finish();
     return PS_OK;
 }
 
@@ -465,22 +479,55 @@ int realign(Runtime* rt, Batch& b) {
     return PS_OK;
 }
 
-// ScoreAlignments, cpp/MakeMutations.cpp:148-195
+// run fn(k) for k in [0, n) on up to 32 host threads (disjoint outputs; the GPU work of a batched call is enqueued by the caller)
+void par_for(int n, const std::function<void(int)>& fn) {
+    if (n <= 1) { if (n == 1) fn(0); return; }
+    const int nth = std::min(n, 32);
+    std::atomic<int> next(0);
+    auto work = [&] { for (int k = next++; k < n; k = next++) fn(k); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; t++) th.emplace_back(work);
+    work();
+    for (std::thread& x : th) x.join();
+}
+
+// ScoreAlignments, cpp/MakeMutations.cpp:148-195, for several AlignData in one launch chain (independent regions in lock-step)
+int score_alignments_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<double*>& scores, const std::vector<double*>& likes) {
+    std::vector<JobSpec> specs;
+    for (Align* a : as)
+        for (int e = 0; e < a->E; e++) {
+            JobSpec s;
+            s.a = a; s.ev = e; s.states = &a->states;
+            s.ra = a->d_ra + a->off[e]; s.rl = a->d_rl + a->off[e]; s.ri = a->d_ri + a->off[e]; s.out = a->d_out + e;
+            specs.push_back(s);
+        }
+    if (specs.empty()) return PS_OK;
+    Batch b;
+    PS_TRY(b.build(rt, specs, 1, 0));
+    PS_TRY(realign(rt, b));
+    std::vector<JobOut*> outs(as.size(), nullptr);
+    for (size_t k = 0; k < as.size(); k++) {
+        as[k]->host_refs_valid = false;
+        if (as[k]->E) PS_TRY(rt->down(&outs[k], as[k]->d_out, (size_t)as[k]->E));
+    }
+    bool any_likes = false;
+    for (size_t k = 0; k < as.size(); k++) if (likes[k]) { any_likes = true; PS_TRY(as[k]->refs_to_host_async(rt)); }
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    for (size_t k = 0; k < as.size(); k++)
+        for (int e = 0; e < as[k]->E; e++) scores[k][e] = std::max(outs[k][e].best, 0.0);  // Alignment::getMax, cpp/Alignment.h:127-130
+    if (any_likes)
+        par_for((int)as.size(), [&](int k) {
+            Align* a = as[k];
+            if (!likes[k]) return;
+            a->refs_finish();
+            for (int e = 0; e < a->E; e++) accumulate_likes(a->h_ra.data() + a->off[e], a->h_rl.data() + a->off[e], a->n[e], (int)a->states.size(), likes[k]);
+        });
+    return PS_OK;
+}
+
 int score_alignments(Runtime* rt, Align* a, double* scores, double* likes) {
     if (!a->E) return PS_OK;
-    Batch b;
-    PS_TRY(a->base_batch(rt, &b, 1, 0));
-    PS_TRY(realign(rt, b));
-    a->host_refs_valid = false;
-    JobOut* out = nullptr;
-    PS_TRY(rt->down(&out, a->d_out, (size_t)a->E));
-    PS_HIP(hipStreamSynchronize(rt->stream));
-    for (int e = 0; e < a->E; e++) scores[e] = std::max(out[e].best, 0.0);  // Alignment::getMax, cpp/Alignment.h:127-130
-    if (likes) {
-        PS_TRY(a->refs_to_host(rt));
-        for (int e = 0; e < a->E; e++) accumulate_likes(a->h_ra.data() + a->off[e], a->h_rl.data() + a->off[e], a->n[e], (int)a->states.size(), likes);
-    }
-    return PS_OK;
+    return score_alignments_multi(rt, {a}, {scores}, {likes});
 }
 
 // the `likes` loop of ScoreAlignments, cpp/MakeMutations.cpp:168-189 (one event)
@@ -523,121 +570,181 @@ static void edited_window(const std::string& b, const Mut& m, int sidx, int ncol
     }
 }
 
-// ScoreMutations, cpp/MakeMutations.cpp:23-69
-int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::vector<Mut>* out) {
-    Tick tk("score_mutations");
-    *out = muts;
-    for (Mut& m : *out) m.score = -1e-6;
+namespace {
+// host-side description of one AlignData's edit list for k_old / k_score
+struct EditPlan {
+    int M = 0, ncolmax = 1, extra = 0, nr0 = 0;
+    std::vector<int> start, mlen, cm, ncol, skip, oldidx, states, r0s, cls[4];
+    int rc = PS_OK;
+};
+}  // namespace
+
+static void plan_edits(const Align* a, const std::vector<Mut>& muts, EditPlan* p) {
     const int M = (int)muts.size();
-    for (const Mut& m : muts) if (m.start < 0) return fail(PS_ERR_BAD_ARG, "negative mutation start");
-    if (!a->E) return PS_OK;
+    p->M = M;
+    for (const Mut& m : muts) if (m.start < 0) { p->rc = PS_ERR_BAD_ARG; return; }
     const int64_t L = (int64_t)a->bases.size();
     const int C = (int)a->states.size();
     const int WS = a->par.scoring_width;
-    if (WS < 0) return fail(PS_ERR_BAD_ARG, "scoring_width < 0");
-    // per-edit geometry
-    std::vector<int> h_start(M), h_mlen(M), h_cm(M), h_ncol(M), h_skip(M), h_oldidx(M);
+    p->start.resize(M); p->mlen.resize(M); p->cm.resize(M); p->ncol.resize(M); p->skip.resize(M); p->oldidx.resize(M);
     int ncolmax = 1, extra = 0;
     for (int i = 0; i < M; i++) {
         const Mut& m = muts[i];
-        h_start[i] = m.start; h_mlen[i] = (int)m.mut.size();
-        h_skip[i] = (int64_t)m.start > L ? 1 : 0;  // "sanity check", cpp/MakeMutations.cpp:46-47
+        p->start[i] = m.start; p->mlen[i] = (int)m.mut.size();
+        p->skip[i] = (int64_t)m.start > L ? 1 : 0;  // "sanity check", cpp/MakeMutations.cpp:46-47
         const bool copy = (int64_t)m.start >= L;
         const int64_t cut = std::min<int64_t>(L, (int64_t)m.start + (int64_t)m.orig.size());
         const int64_t Lm = copy ? L : (int64_t)m.start + (int64_t)m.mut.size() + (L - cut);
         const int Cm = Lm >= 5 ? (int)(Lm - 4) : 0;
-        h_cm[i] = Cm;
+        p->cm[i] = Cm;
         const int sidx = std::max(m.start - 4, 0);
         int ncol = std::min<int64_t>((int64_t)m.mut.size() + 6, std::max<int64_t>(0, (int64_t)Cm - sidx));
-        if (WS == 0 || h_skip[i]) ncol = 0;  // stripe_width 0 makes fillColumn a no-op, cpp/Alignment.cpp:118-119
-        h_ncol[i] = ncol;
+        if (WS == 0 || p->skip[i]) ncol = 0;  // stripe_width 0 makes fillColumn a no-op, cpp/Alignment.cpp:118-119
+        p->ncol[i] = ncol;
         ncolmax = std::max(ncolmax, ncol);
-        if (!h_skip[i]) extra = std::max(extra, sidx + ncol + 1 - (C + 1));
+        if (!p->skip[i]) extra = std::max(extra, sidx + ncol + 1 - (C + 1));
     }
-    extra = std::max(extra, 0) + 2;
-    if (ncolmax > 64 && WS > 511) return fail(PS_ERR_UNSUPPORTED, "edit longer than 58 bases with scoring_width > 511");
-    // Alignment::update for every event: enqueued now, so that the fills run while the host prepares the edit tables
-    tk.lap("edit sizes");
-    Batch b;
-    PS_TRY(a->base_batch(rt, &b, 2, extra));
-    PS_TRY(realign(rt, b));
-    a->host_refs_valid = false;
-    tk.lap("realign enqueue");
-    std::vector<int> h_states((size_t)M * ncolmax, -1);
+    p->ncolmax = ncolmax;
+    p->extra = std::max(extra, 0) + 2;
+}
+
+// second half of the plan (runs on host threads while the GPU realigns): edited states, distinct r0, size classes
+static void plan_tables(const Align* a, const std::vector<Mut>& muts, EditPlan* p, int nth) {
+    const int M = p->M, ncolmax = p->ncolmax;
+    const int64_t L = (int64_t)a->bases.size();
+    p->states.assign((size_t)M * ncolmax, -1);
     {
         auto work = [&](int lo, int hi) {
             for (int i = lo; i < hi; i++)
-                if (h_ncol[i] > 0) edited_window(a->bases, muts[i], std::max(muts[i].start - 4, 0), h_ncol[i], h_states.data() + (size_t)i * ncolmax);
+                if (p->ncol[i] > 0) edited_window(a->bases, muts[i], std::max(muts[i].start - 4, 0), p->ncol[i], p->states.data() + (size_t)i * ncolmax);
         };
-        const int nth = M >= 4096 ? 8 : 1;   // Refine-sized lists: split over a few host threads (disjoint outputs)
+        if (M < 4096) nth = 1;   // Refine-sized lists: split over a few host threads (disjoint outputs)
         std::vector<std::thread> th;
         for (int t = 1; t < nth; t++) th.emplace_back(work, (int)((int64_t)M * t / nth), (int)((int64_t)M * (t + 1) / nth));
         work(0, (int)((int64_t)M / nth));
         for (std::thread& x : th) x.join();
     }
-    // distinct r0 = max(start - 3, 1)
-    std::vector<int> r0s;
-    {
-        std::vector<int> idx((size_t)std::max<int64_t>(L, 4) + 2, -1);   // r0 <= L - 3 for every edit that is not skipped
-        for (int i = 0; i < M; i++) {
-            if (h_skip[i]) { h_oldidx[i] = 0; continue; }
-            const int r0 = std::max(muts[i].start - 3, 1);
-            int& at = idx[r0];
-            if (at < 0) { at = (int)r0s.size(); r0s.push_back(r0); }
-            h_oldidx[i] = at;
+    std::vector<int> idx((size_t)std::max<int64_t>(L, 4) + 2, -1);   // r0 <= L - 3 for every edit that is not skipped
+    for (int i = 0; i < M; i++) {
+        if (p->skip[i]) { p->oldidx[i] = 0; continue; }
+        const int r0 = std::max(muts[i].start - 3, 1);
+        int& at = idx[r0];
+        if (at < 0) { at = (int)p->r0s.size(); p->r0s.push_back(r0); }
+        p->oldidx[i] = at;
+    }
+    p->nr0 = (int)p->r0s.size();
+    for (int i = 0; i < M; i++) {
+        const int nc = p->ncol[i];
+        p->cls[nc <= 8 ? 0 : nc <= 16 ? 1 : nc <= 32 ? 2 : 3].push_back(i);
+    }
+}
+
+// ScoreMutations, cpp/MakeMutations.cpp:23-69, for several AlignData at once: one realign launch chain over all their
+// events (forward + backward of one event share a workgroup), then the edit scoring of each
+int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
+                          const std::vector<std::vector<Mut>*>& outs) {
+    Tick tk("score_mutations");
+    const int R = (int)as.size();
+    std::vector<EditPlan> plan(R);
+    for (int k = 0; k < R; k++) {
+        *outs[k] = *muts[k];
+        for (Mut& m : *outs[k]) m.score = -1e-6;
+        if (as[k]->par.scoring_width < 0) return fail(PS_ERR_BAD_ARG, "scoring_width < 0");
+        plan_edits(as[k], *muts[k], &plan[k]);
+        if (plan[k].rc != PS_OK) return fail(plan[k].rc, "negative mutation start");
+        if (plan[k].ncolmax > 64 && as[k]->par.scoring_width > 511) return fail(PS_ERR_UNSUPPORTED, "edit longer than 58 bases with scoring_width > 511");
+    }
+    tk.lap("edit sizes");
+    // Alignment::update for every event of every AlignData: enqueued now, so that the fills run while the host prepares the edit tables
+    std::vector<JobSpec> specs;
+    std::vector<int> job0(R, 0);
+    int extra = 0;
+    for (int k = 0; k < R; k++) {
+        Align* a = as[k];
+        job0[k] = (int)specs.size();
+        extra = std::max(extra, plan[k].extra);
+        for (int e = 0; e < a->E; e++) {
+            JobSpec s;
+            s.a = a; s.ev = e; s.states = &a->states;
+            s.ra = a->d_ra + a->off[e]; s.rl = a->d_rl + a->off[e]; s.ri = a->d_ri + a->off[e]; s.out = a->d_out + e;
+            specs.push_back(s);
         }
     }
-    // size classes by new-column count
-    std::vector<int> cls[4];
-    for (int i = 0; i < M; i++) {
-        const int nc = h_ncol[i];
-        cls[nc <= 8 ? 0 : nc <= 16 ? 1 : nc <= 32 ? 2 : 3].push_back(i);
-    }
+    if (specs.empty()) return PS_OK;
+    Batch b;
+    PS_TRY(b.build(rt, specs, 2, extra));
+    PS_TRY(realign(rt, b));
+    for (Align* a : as) a->host_refs_valid = false;
+    tk.lap("realign enqueue");
+    par_for(R, [&](int k) { plan_tables(as[k], *muts[k], &plan[k], R == 1 ? 8 : (R <= 4 ? 4 : 1)); });
     tk.lap("edit geometry");
-    // upload edit tables
-    const int nr0 = (int)r0s.size();
+    // upload the edit tables of all AlignData in one block
+    size_t ints = 16, dbls = 1;
+    for (int k = 0; k < R; k++) {
+        const EditPlan& p = plan[k];
+        ints += (size_t)p.M * 7 + (size_t)p.M * p.ncolmax + p.nr0 + 16;
+        dbls += (size_t)as[k]->E * std::max(p.nr0, 1) + (size_t)as[k]->E * std::max(p.M, 1) + std::max(p.M, 1);
+    }
     DBuf& mb = rt->buf("mutint");
-    const size_t ints = (size_t)M * 7 + (size_t)M * ncolmax + nr0 + 16;
     PS_TRY(mb.ensure(ints * sizeof(int)));
+    DBuf& db = rt->buf("mutdbl");
+    PS_TRY(db.ensure(dbls * sizeof(double)));
     int* dp = mb.as<int>();
+    double* dd = db.as<double>();
     std::vector<int> stage;
     stage.reserve(ints);
     auto push = [&](const std::vector<int>& v) { int* r = dp + stage.size(); stage.insert(stage.end(), v.begin(), v.end()); return r; };
-    ScoreArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.nitems_per_job = M; sa.ncolmax = ncolmax; sa.ws = WS; sa.nr0 = nr0;
-    sa.m_start = push(h_start); sa.m_mlen = push(h_mlen); sa.m_cm = push(h_cm); sa.m_ncol = push(h_ncol);
-    sa.m_skip = push(h_skip); sa.m_oldidx = push(h_oldidx); sa.m_states = push(h_states); sa.r0 = push(r0s);
-    const int* cls_items[4]; int cls_count[4];
-    for (int k = 0; k < 4; k++) { cls_items[k] = push(cls[k]); cls_count[k] = (int)cls[k].size(); }
+    std::vector<ScoreArgs> sas(R);
+    std::vector<std::array<const int*, 4>> cls_items(R);
+    std::vector<std::array<int, 4>> cls_count(R);
+    for (int k = 0; k < R; k++) {
+        const EditPlan& p = plan[k];
+        ScoreArgs& sa = sas[k];
+        memset(&sa, 0, sizeof(sa));
+        sa.job0 = job0[k]; sa.njobs = as[k]->E;
+        sa.nitems_per_job = p.M; sa.ncolmax = p.ncolmax; sa.ws = as[k]->par.scoring_width; sa.nr0 = p.nr0;
+        sa.m_start = push(p.start); sa.m_mlen = push(p.mlen); sa.m_cm = push(p.cm); sa.m_ncol = push(p.ncol);
+        sa.m_skip = push(p.skip); sa.m_oldidx = push(p.oldidx); sa.m_states = push(p.states); sa.r0 = push(p.r0s);
+        for (int q = 0; q < 4; q++) { cls_items[k][q] = push(p.cls[q]); cls_count[k][q] = (int)p.cls[q].size(); }
+        sa.old = dd; dd += (size_t)as[k]->E * std::max(p.nr0, 1);
+        sa.delta = dd; dd += (size_t)as[k]->E * std::max(p.M, 1);
+        sa.score = dd; dd += std::max(p.M, 1);
+    }
     PS_TRY(rt->up(dp, stage.data(), stage.size() * sizeof(int)));
-    DBuf& db = rt->buf("mutdbl");
-    const size_t dbl = (size_t)a->E * std::max(nr0, 1) + (size_t)a->E * std::max(M, 1) + std::max(M, 1);
-    PS_TRY(db.ensure(dbl * sizeof(double)));
-    sa.old = db.as<double>(); sa.delta = sa.old + (size_t)a->E * std::max(nr0, 1); sa.score = sa.delta + (size_t)a->E * std::max(M, 1);
     tk.lap("upload");
     if (tk.on) { PS_HIP(hipStreamSynchronize(rt->stream)); }
     tk.lap("realign fwd+back (rest)");
     PS_TRY(launch_lb(rt, b.d, 1, b.maxlbn));
-    if (M) {
+    std::vector<double*> sc(R, nullptr);
+    for (int k = 0; k < R; k++) {
+        const EditPlan& p = plan[k];
+        if (!p.M || !as[k]->E) continue;
         if (rt->prof_on) {
             // per (event, edit) item  16(Bs+1) + 16 Br + 24(Bs+c) + 32 Br / k + 8
             double t = 0;
-            const double Bs = 2.0 * WS + 1, Br = 2.0 * a->par.realign_width + 1;
-            const double k = M ? (double)M / std::max(nr0, 1) : 1;
-            for (int i = 0; i < M; i++) t += 16 * (Bs + 1) + 16 * Br + 24 * (Bs + h_mlen[i] + 6) + 32 * Br / k + 8;
-            rt->prof["score"].bytes += t * a->E;
+            const double Bs = 2.0 * sas[k].ws + 1, Br = 2.0 * as[k]->par.realign_width + 1;
+            const double kk = (double)p.M / std::max(p.nr0, 1);
+            for (int i = 0; i < p.M; i++) t += 16 * (Bs + 1) + 16 * Br + 24 * (Bs + p.mlen[i] + 6) + 32 * Br / kk + 8;
+            rt->prof["score"].bytes += t * as[k]->E;
         }
-        PS_TRY(launch_score(rt, b.d, sa, cls_items, cls_count));
-        double* sc = nullptr;
-        PS_TRY(rt->down(&sc, sa.score, (size_t)M));
-        PS_HIP(hipStreamSynchronize(rt->stream));
-        for (int i = 0; i < M; i++) (*out)[i].score = sc[i];
-        tk.lap("score edits");
-    } else {
-        PS_HIP(hipStreamSynchronize(rt->stream));
+        PS_TRY(launch_score(rt, b.d, sas[k], cls_items[k].data(), cls_count[k].data()));
+        PS_TRY(rt->down(&sc[k], sas[k].score, (size_t)p.M));
     }
+    PS_HIP(hipStreamSynchronize(rt->stream));
+    for (int k = 0; k < R; k++)
+        if (sc[k]) for (int i = 0; i < plan[k].M; i++) (*outs[k])[i].score = sc[k][i];
+    tk.lap("score edits");
     return PS_OK;
+}
+
+int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::vector<Mut>* out) {
+    if (!a->E) {
+        *out = muts;
+        for (Mut& m : *out) m.score = -1e-6;
+        for (const Mut& m : muts) if (m.start < 0) return fail(PS_ERR_BAD_ARG, "negative mutation start");
+        return PS_OK;
+    }
+    return score_mutations_multi(rt, {a}, {&muts}, {out});
 }
 
 // FindPointMutations, cpp/FindMutations.cpp:191-234
@@ -664,10 +771,12 @@ static bool by_score_desc(const Mut& x, const Mut& y) { return x.score > y.score
 
 // MakeMutations, cpp/MakeMutations.cpp:74-146.  std::sort with the same comparator on the same
 // libstdc++ gives the reference's (unstable) order for tied scores.
-int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {
-    Tick tk("make_mutations");
+// One greedy pass (host only): sorts, applies the positive edits, returns the mutated-base count and the edits that
+// were disabled on the way (the reference re-scores and recurses on those when there are more than ten).
+static int greedy_apply(Align* a, std::vector<Mut>& muts, std::vector<Mut>* later) {
     const int spacing = 10;
     int nb = 0;
+    later->clear();
     {
         // std::sort on indices makes exactly the comparisons (hence the same permutation, ties included) it would
         // make on the structs themselves, without moving two std::strings per swap
@@ -681,11 +790,10 @@ int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {
         for (int k : order) kept.push_back(std::move(muts[k]));
         muts.swap(kept);
     }
-    if (muts.empty()) { *nbases = 0; return PS_OK; }
-    std::vector<Mut> later;
+    if (muts.empty()) return 0;
     bool changed = false;
     for (size_t i = 0; i < muts.size(); i++) {
-        if (muts[i].score < 0) { later.push_back(muts[i]); continue; }
+        if (muts[i].score < 0) { later->push_back(muts[i]); continue; }
         a->bases = apply_edit(a->bases, muts[i]);
         changed = true;
         nb += (int)std::max(muts[i].orig.size(), muts[i].mut.size());
@@ -698,15 +806,43 @@ int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {
         }
     }
     if (changed) a->states = states_of(a->bases);
-    tk.lap("greedy apply");
-    if (later.size() > 10) {
-        std::vector<Mut> rescored;
-        PS_TRY(score_mutations(rt, a, later, &rescored));
-        int more = 0;
-        PS_TRY(make_mutations(rt, a, rescored, &more));
-        nb += more;
+    return nb;
+}
+
+// MakeMutations for several AlignData in lock-step: the greedy passes run on host threads, every round of re-scoring
+// is one batched ScoreMutations over the AlignData that still have more than ten disabled edits
+int make_mutations_multi(Runtime* rt, const std::vector<Align*>& as, std::vector<std::vector<Mut>> muts, std::vector<int>* nbases) {
+    Tick tk("make_mutations");
+    const int R = (int)as.size();
+    nbases->assign(R, 0);
+    std::vector<int> active(R);
+    std::iota(active.begin(), active.end(), 0);
+    std::vector<std::vector<Mut>> later(R);
+    while (!active.empty()) {
+        par_for((int)active.size(), [&](int q) {
+            const int k = active[q];
+            (*nbases)[k] += greedy_apply(as[k], muts[k], &later[k]);
+        });
+        tk.lap("greedy apply");
+        std::vector<int> next;
+        for (int k : active) if (later[k].size() > 10) next.push_back(k);
+        if (next.empty()) break;
+        std::vector<Align*> sa;
+        std::vector<const std::vector<Mut>*> in;
+        std::vector<std::vector<Mut>*> out;
+        for (int k : next) { sa.push_back(as[k]); in.push_back(&later[k]); out.push_back(&muts[k]); }
+        PS_TRY(score_mutations_multi(rt, sa, in, out));
+        active.swap(next);
     }
-    *nbases = nb;
+    return PS_OK;
+}
+
+int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {
+    std::vector<int> nb;
+    std::vector<std::vector<Mut>> in(1);
+    in[0] = std::move(muts);
+    PS_TRY(make_mutations_multi(rt, {a}, std::move(in), &nb));
+    *nbases = nb[0];
     return PS_OK;
 }
 

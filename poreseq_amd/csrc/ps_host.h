@@ -2,6 +2,8 @@
 #ifndef PS_HOST_H_
 #define PS_HOST_H_
 
+#include <functional>
+
 #include "ps_internal.h"
 
 namespace ps {
@@ -19,6 +21,11 @@ struct Align;
 
 void rand_seed(unsigned seed);   // per-thread generator of ViterbiMutate's deviates (ps_find.cpp)
 int rand_next();
+struct RandState;                // an explicit generator state (one per region of a lock-step driver)
+RandState* rand_state_new(unsigned seed);
+void rand_state_free(RandState* r);
+void rand_state_seed(RandState* r, unsigned seed);
+int rand_state_next(RandState* r);   // nullptr: the calling thread's generator
 
 struct JobSpec {
     Align* a = nullptr;                                  // owner of the event data (one batch may mix several AlignData)
@@ -66,6 +73,9 @@ struct Align {
                const ps_params* params);
     int base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra);
     int refs_to_host(Runtime* rt);
+    int refs_to_host_async(Runtime* rt);   // enqueue; refs_finish() after the stream has been synchronised
+    void refs_finish();
+    double *pend_ra = nullptr, *pend_rl = nullptr;
 };
 
 std::vector<int> states_of(const std::string& bases);
@@ -74,6 +84,17 @@ void accumulate_likes(const double* ra, const double* rl, int n, int C, double* 
 
 int realign(Runtime* rt, Batch& b);
 int score_alignments(Runtime* rt, Align* a, double* scores, double* likes);
+// the *_multi forms run the same call for several AlignData (independent regions) in one launch chain
+void par_for(int n, const std::function<void(int)>& fn);
+int score_alignments_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<double*>& scores, const std::vector<double*>& likes);
+int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<std::string>*>& seeds,
+                         const std::vector<std::vector<Mut>*>& outs);
+int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<RandState*>& rngs, int nkeep, double skip, double stay,
+                         double mmin, double mmax, const std::vector<std::vector<std::string>*>& outs);
+int live_runtimes();   // host threads that currently own a runtime
+int make_mutations_multi(Runtime* rt, const std::vector<Align*>& as, std::vector<std::vector<Mut>> muts, std::vector<int>* nbases);
+int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
+                          const std::vector<std::vector<Mut>*>& outs);
 int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::vector<Mut>* out);
 void find_point_mutations(const Align* a, std::vector<Mut>* out);
 int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases);

@@ -181,6 +181,7 @@ int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int
 int launch_backtrace(Runtime* rt, const BatchD& b, int maxn);
 
 struct ScoreArgs {
+    int job0, njobs;           // the AlignData's jobs inside the batch
     int nitems_per_job;        // M
     int ncolmax;               // max new columns of any edit
     int ws;                    // scoring_width
@@ -205,12 +206,16 @@ int launch_begin(Runtime* rt, const BatchD& b);
 int sw_device(Runtime* rt, const std::string& s1, const std::string& s2, int* score, double* accuracy,
               std::vector<int>* inds1, std::vector<int>* inds2);
 
-// Viterbi (ps_viterbi.hip)
-struct VitStepH { int refind; };
-int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin /*[T][E][4]: lvl, sd, logsd, present*/,
-                   const double* d_model, int nkeep, double skip, double stay, double mmin, double mmax,
-                   void (*draw)(double* /*[nkeep][T]*/, size_t) /* draws the deviates; called while the recursion runs */,
-                   std::vector<std::vector<int>>* paths);
+// Viterbi (ps_viterbi.hip): one region of a batched ViterbiMutate call, host side
+struct VitRegionH {
+    int E = 0, T = 0;
+    const double* obsin = nullptr;       // [T][E][4]: level, sd, log sd, present
+    const double* d_model = nullptr;     // device, [E][6][1024]
+    void* rng = nullptr;                 // the region's generator state, handed to draw()
+    void (*draw)(void* rng, double* out /*[nkeep][T]*/, size_t n) = nullptr;
+};
+int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, int nkeep, double skip, double stay, double mmin, double mmax,
+                         std::vector<std::vector<std::vector<int>>>* paths);
 
 void prof_begin(Runtime* rt);
 void prof_end(Runtime* rt, const char* name, double alg_bytes);

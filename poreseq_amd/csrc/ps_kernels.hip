@@ -827,7 +827,7 @@ __device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, 
 
 // old score for each distinct r0 = max(start - 3, 1) ; grid (nr0, njobs), block 64
 __global__ __launch_bounds__(64) void k_old(BatchD b, ScoreArgs a) {
-    const JobD& J = b.jobs[blockIdx.y];
+    const JobD& J = b.jobs[a.job0 + blockIdx.y];
     if (J.out->inert) return;
     const int r0 = a.r0[blockIdx.x];
     const double v = colmax_pair(b, J, r0, J.C - r0 + 1, threadIdx.x, 64);
@@ -844,8 +844,8 @@ __global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int*
     __shared__ double s_carry[(G == 64) ? 4 * 1024 : 1];   // last column of a 64-column chunk, per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / G, c = lane % G;
-    const int job = blockIdx.y;
-    const JobD& J = b.jobs[job];
+    const int job = blockIdx.y;   // within the AlignData's own jobs, which start at a.job0 in the batch
+    const JobD& J = b.jobs[a.job0 + job];
     const int it = (blockIdx.x * 4 + wave) * IPW + g;
     const bool have = it < nitems;
     const int m = have ? items[it] : 0;
@@ -1107,9 +1107,10 @@ int launch_begin(Runtime* rt, const BatchD& b) {
 }
 
 int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* const cls_items[4], const int cls_count[4]) {
-    if (!b.njobs || !a.nitems_per_job) return PS_OK;
+    const int njobs = a.njobs;   // the jobs [a.job0, a.job0 + njobs) of the batch belong to the AlignData being scored
+    if (!njobs || !a.nitems_per_job) return PS_OK;
     if (a.nr0 > 0) {
-        hipLaunchKernelGGL(k_old, dim3(a.nr0, b.njobs), dim3(64), 0, rt->stream, b, a);
+        hipLaunchKernelGGL(k_old, dim3(a.nr0, njobs), dim3(64), 0, rt->stream, b, a);
         PS_LAUNCH_CHECK();
     }
     prof_begin(rt);
@@ -1117,7 +1118,7 @@ int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* co
         const int n = cls_count[k];
         if (!n) continue;
         const int G = 8 << k, ipb = 4 * (64 / G);
-        dim3 grid((n + ipb - 1) / ipb, b.njobs), block(256);
+        dim3 grid((n + ipb - 1) / ipb, njobs), block(256);
         if (k == 0) hipLaunchKernelGGL(k_score<8>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
         else if (k == 1) hipLaunchKernelGGL(k_score<16>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
         else if (k == 2) hipLaunchKernelGGL(k_score<32>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
@@ -1125,7 +1126,7 @@ int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* co
         PS_LAUNCH_CHECK();
     }
     prof_end(rt, "score", 0.0);
-    hipLaunchKernelGGL(k_reduce, dim3((a.nitems_per_job + 255) / 256), dim3(256), 0, rt->stream, a, b.njobs);
+    hipLaunchKernelGGL(k_reduce, dim3((a.nitems_per_job + 255) / 256), dim3(256), 0, rt->stream, a, njobs);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }

@@ -29,19 +29,29 @@ __device__ __forceinline__ double emission_v(const ModelRowV& m, double x, doubl
     return l;
 }
 
-constexpr int VMAXE = 64;  // events handled per position without spilling to the slow path
+// one region (AlignData) of a batched ViterbiMutate call
+struct VitReg {
+    const double* model;   // [E][6][1024]
+    int E, T;              // events, reference positions kept
+    int64_t in_off;        // into obsin (doubles)
+    int64_t t_off;         // first position of the region in obs / eobs / bp / lfwd (rows of 1024)
+};
 
-// obsin[t][e][4] = {level mean, sd mean, log(sd mean), present}; obs[t][1024]
-__global__ __launch_bounds__(256) void k_vit_obs(const double* __restrict__ obsin, const double* __restrict__ model,
-                                                 int E, double log2pi, double* __restrict__ obs, double* __restrict__ eobs) {
+// obsin[t][e][4] = {level mean, sd mean, log(sd mean), present}; obs[t][1024].  VMAXE = events one thread can sort in its
+// private array: 64 covers the reference's max_coverage of 30 reads (60 events); 256 is the slow build for deeper stacks
+template <int VMAXE>
+__global__ __launch_bounds__(256) void k_vit_obs(const VitReg* __restrict__ regs, const int* __restrict__ pos_reg, const double* __restrict__ obsin,
+                                                 double log2pi, double* __restrict__ obs, double* __restrict__ eobs) {
     const int t = blockIdx.x;
-    const double* in = obsin + (size_t)t * E * 4;
+    const VitReg R = regs[pos_reg[t]];
+    const int E = R.E;
+    const double* in = obsin + R.in_off + (size_t)(t - R.t_off) * E * 4;
     for (int st = threadIdx.x; st < NS; st += 256) {
         double v[VMAXE];
         int nl = 0;
         for (int e = 0; e < E; e++) {
             if (in[e * 4 + 3] == 0.0) continue;
-            const double* gm = model + (size_t)e * 6 * NS;
+            const double* gm = R.model + (size_t)e * 6 * NS;
             ModelRowV m = {gm[st], gm[NS + st], gm[2 * NS + st], gm[3 * NS + st], gm[4 * NS + st], gm[5 * NS + st]};
             const double l = emission_v(m, in[e * 4 + 0], in[e * 4 + 1], in[e * 4 + 2], log2pi);
             // insertion into ascending order (std::sort result is unique for distinct/equal doubles)
@@ -135,10 +145,19 @@ __device__ __forceinline__ double below(double x) {
 // (normvec, cpp/Viterbi.cpp:101).  Only ratios within one step's vector are ever used (randbp
 // renormalises its own products), so here the vector is rescaled every 8 steps by an exact power of
 // two: it stays in range, no rounding is added, and no reduce -> divide chain sits on the step path.
-__global__ __launch_bounds__(1024) void k_vit_steps(const double* __restrict__ obs, const double* __restrict__ eobs, int T, double skip, double stay,
-                                                    double lskip, double lstay, double l25,
-                                                    short* __restrict__ bp, double* __restrict__ lfwd_out,
-                                                    double* __restrict__ lik_final, int keep_fwd) {
+__global__ __launch_bounds__(1024) void k_vit_steps(const VitReg* __restrict__ regs, const double* __restrict__ obs_all, const double* __restrict__ eobs_all,
+                                                    double skip, double stay, double lskip, double lstay, double l25,
+                                                    short* __restrict__ bp_all, double* __restrict__ lfwd_all,
+                                                    double* __restrict__ lik_final_all, int keep_fwd) {
+    // one workgroup per region of the batch
+    const int T = regs[blockIdx.x].T;
+    const size_t roff = (size_t)regs[blockIdx.x].t_off * NS;
+    const double* __restrict__ obs = obs_all + roff;
+    const double* __restrict__ eobs = eobs_all + roff;
+    short* __restrict__ bp = bp_all + roff;
+    double* __restrict__ lfwd_out = lfwd_all + (keep_fwd ? roff : 0);
+    double* __restrict__ lik_final = lik_final_all + (size_t)blockIdx.x * NS;
+    if (T <= 0) return;
     __shared__ double s_lik[2][NS + NS / 32], s_fwd[2][NS + NS / 32];
     __shared__ Fam s_fam[336];
     __shared__ double s_red[16];
@@ -288,9 +307,16 @@ __device__ __forceinline__ double wave_scan(double v, int lane) {
 constexpr int VT_THREADS = 512;                 // threads per back-trace
 constexpr int VT_SPT = NS / VT_THREADS;         // consecutive states per thread (2)
 constexpr int VT_WAVES = VT_THREADS / 64;       // 8 waves: two per SIMD, half the per-wave instruction stream of 4 x 4 states
-__global__ __launch_bounds__(VT_THREADS) void k_vit_trace(const double* __restrict__ lfwd, int T, int start, double skip, double stay,
-                                                         const double* __restrict__ atten, const double* __restrict__ rnd,
-                                                         short* __restrict__ path) {
+__global__ __launch_bounds__(VT_THREADS) void k_vit_trace(const VitReg* __restrict__ regs, const double* __restrict__ lfwd_all, const int* __restrict__ starts,
+                                                         double skip, double stay, const double* __restrict__ atten,
+                                                         const double* __restrict__ rnd_all, short* __restrict__ path_all) {
+    // grid (nkeep, regions); a region's deviates / paths are [nkeep][T] blocks at nkeep * t_off
+    const int T = regs[blockIdx.y].T;
+    if (T <= 0) return;
+    const int start = starts[blockIdx.y];
+    const double* __restrict__ lfwd = lfwd_all + (size_t)regs[blockIdx.y].t_off * NS;
+    const double* __restrict__ rnd = rnd_all + (size_t)gridDim.x * regs[blockIdx.y].t_off;
+    short* __restrict__ path = path_all + (size_t)gridDim.x * regs[blockIdx.y].t_off;
     __shared__ double s_wtot[2][VT_WAVES];
     __shared__ int s_pick[2][VT_WAVES];
     const int k = blockIdx.x, t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -338,71 +364,102 @@ __global__ __launch_bounds__(VT_THREADS) void k_vit_trace(const double* __restri
     }
 }
 
-int viterbi_device(Runtime* rt, int E, int T, const double* h_obsin, const double* d_model, int nkeep,
-                   double skip, double stay, double mmin, double mmax, void (*draw)(double*, size_t),
-                   std::vector<std::vector<int>>* paths) {
-    paths->clear();
-    if (T <= 0) return PS_OK;
-    if (E > VMAXE) return fail(PS_ERR_UNSUPPORTED, "ViterbiMutate: more than 64 events");
-    PS_TRY(rt->buf("vit_in").ensure((size_t)T * E * 4 * sizeof(double)));
-    PS_TRY(rt->buf("vit_obs").ensure((size_t)T * NS * sizeof(double)));
-    PS_TRY(rt->buf("vit_eobs").ensure((size_t)T * NS * sizeof(double)));
-    PS_TRY(rt->buf("vit_bp").ensure((size_t)T * NS * sizeof(short)));
-    PS_TRY(rt->buf("vit_fwd").ensure((size_t)(nkeep ? T : 1) * NS * sizeof(double)));
-    PS_TRY(rt->buf("vit_lik").ensure(NS * sizeof(double)));
+int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, int nkeep, double skip, double stay, double mmin, double mmax,
+                         std::vector<std::vector<std::vector<int>>>* paths) {
+    const int R = (int)regions.size();
+    paths->assign(R, {});
+    std::vector<VitReg> regs(R);
+    int64_t ttot = 0, intot = 0;
+    int maxE = 0;
+    for (int r = 0; r < R; r++) {
+        regs[r].model = regions[r].d_model; regs[r].E = regions[r].E; regs[r].T = regions[r].T;
+        regs[r].in_off = intot; regs[r].t_off = ttot;
+        intot += (int64_t)regions[r].T * regions[r].E * 4; ttot += regions[r].T;
+        maxE = std::max(maxE, regions[r].E);
+    }
+    if (ttot <= 0) return PS_OK;
+    if (maxE > 256) return fail(PS_ERR_UNSUPPORTED, "ViterbiMutate: more than 256 events");
+    std::vector<int> pos_reg((size_t)ttot);
+    for (int r = 0; r < R; r++) std::fill(pos_reg.begin() + regs[r].t_off, pos_reg.begin() + regs[r].t_off + regs[r].T, r);
+    PS_TRY(rt->buf("vit_regs").ensure(R * sizeof(VitReg)));
+    PS_TRY(rt->buf("vit_posreg").ensure((size_t)ttot * sizeof(int)));
+    PS_TRY(rt->buf("vit_in").ensure((size_t)std::max<int64_t>(intot, 1) * sizeof(double)));
+    PS_TRY(rt->buf("vit_obs").ensure((size_t)ttot * NS * sizeof(double)));
+    PS_TRY(rt->buf("vit_eobs").ensure((size_t)ttot * NS * sizeof(double)));
+    PS_TRY(rt->buf("vit_bp").ensure((size_t)ttot * NS * sizeof(short)));
+    PS_TRY(rt->buf("vit_fwd").ensure((size_t)(nkeep ? ttot : 1) * NS * sizeof(double)));
+    PS_TRY(rt->buf("vit_lik").ensure((size_t)R * NS * sizeof(double)));
+    VitReg* d_regs = rt->buf("vit_regs").as<VitReg>();
+    int* d_posreg = rt->buf("vit_posreg").as<int>();
     double* d_in = rt->buf("vit_in").as<double>();
     double* d_obs = rt->buf("vit_obs").as<double>();
     double* d_eobs = rt->buf("vit_eobs").as<double>();
     short* d_bp = rt->buf("vit_bp").as<short>();
     double* d_fwd = rt->buf("vit_fwd").as<double>();
     double* d_lik = rt->buf("vit_lik").as<double>();
-    PS_TRY(rt->up(d_in, h_obsin, (size_t)T * E * 4 * sizeof(double)));
+    PS_TRY(rt->up(d_regs, regs.data(), R * sizeof(VitReg)));
+    PS_TRY(rt->up(d_posreg, pos_reg.data(), (size_t)ttot * sizeof(int)));
+    for (int r = 0; r < R; r++)
+        if (regions[r].T) PS_TRY(rt->up(d_in + regs[r].in_off, regions[r].obsin, (size_t)regions[r].T * regions[r].E * 4 * sizeof(double)));
     prof_begin(rt);
-    hipLaunchKernelGGL(k_vit_obs, dim3(T), dim3(256), 0, rt->stream, d_in, d_model, E, std::log(2 * M_PI), d_obs, d_eobs);
-    hipLaunchKernelGGL(k_vit_steps, dim3(1), dim3(1024), 0, rt->stream, d_obs, d_eobs, T, skip, stay, std::log(skip), std::log(stay),
+    if (maxE <= 64) hipLaunchKernelGGL(k_vit_obs<64>, dim3((unsigned)ttot), dim3(256), 0, rt->stream, d_regs, d_posreg, d_in, std::log(2 * M_PI), d_obs, d_eobs);
+    else hipLaunchKernelGGL(k_vit_obs<256>, dim3((unsigned)ttot), dim3(256), 0, rt->stream, d_regs, d_posreg, d_in, std::log(2 * M_PI), d_obs, d_eobs);
+    hipLaunchKernelGGL(k_vit_steps, dim3(R), dim3(1024), 0, rt->stream, d_regs, d_obs, d_eobs, skip, stay, std::log(skip), std::log(stay),
                        std::log(0.25), d_bp, d_fwd, d_lik, nkeep ? 1 : 0);
     PS_HIP(hipGetLastError());
     double* lik = nullptr;
-    PS_TRY(rt->down(&lik, d_lik, (size_t)NS));
-    // the uniform deviates of the stochastic back-traces are drawn on the host while the recursion runs
+    PS_TRY(rt->down(&lik, d_lik, (size_t)R * NS));
+    // the uniform deviates of the stochastic back-traces are drawn on the host while the recursion runs: per region in the
+    // reference's call order (for each kept path, one per back-step, cpp/Viterbi.cpp:108) from the region's own generator
     double* h_rand = nullptr;
     if (nkeep > 0) {
-        h_rand = (double*)rt->stage.alloc((size_t)nkeep * T * sizeof(double));
+        h_rand = (double*)rt->stage.alloc((size_t)nkeep * ttot * sizeof(double));
         if (!h_rand) return fail(PS_ERR_NOMEM, "hipHostMalloc (staging arena)");
-        draw(h_rand, (size_t)nkeep * T);
+        for (int r = 0; r < R; r++) regions[r].draw(regions[r].rng, h_rand + (size_t)nkeep * regs[r].t_off, (size_t)nkeep * regions[r].T);
     }
     PS_HIP(hipStreamSynchronize(rt->stream));
-    const int start = (int)(std::max_element(lik, lik + NS) - lik);
+    std::vector<int> starts(R, 0);
+    for (int r = 0; r < R; r++) starts[r] = (int)(std::max_element(lik + (size_t)r * NS, lik + (size_t)(r + 1) * NS) - (lik + (size_t)r * NS));
     if (nkeep == 0) {
         short* bp = nullptr;
-        PS_TRY(rt->down(&bp, d_bp, (size_t)T * NS));
+        PS_TRY(rt->down(&bp, d_bp, (size_t)ttot * NS));
         PS_HIP(hipStreamSynchronize(rt->stream));
-        prof_end(rt, "viterbi", (double)T * NS * (8.0 * E + 8 + 2));
-        std::vector<int> p(T);
-        int c = start;
-        for (int i = T - 1; i >= 0; i--) { p[i] = c; c = bp[(size_t)i * NS + c]; }
-        paths->push_back(p);
+        prof_end(rt, "viterbi", (double)ttot * NS * (8.0 * maxE + 8 + 2));
+        for (int r = 0; r < R; r++) {
+            if (!regions[r].T) continue;
+            std::vector<int> p(regions[r].T);
+            int c = starts[r];
+            for (int i = regions[r].T - 1; i >= 0; i--) { p[i] = c; c = bp[((size_t)regs[r].t_off + i) * NS + c]; }
+            (*paths)[r].push_back(p);
+        }
         return PS_OK;
     }
     std::vector<double> att(nkeep);
     for (int k = 0; k < nkeep; k++) att[k] = mmin + (mmax - mmin) * k / (double)nkeep;
     PS_TRY(rt->buf("vit_att").ensure(nkeep * sizeof(double)));
-    PS_TRY(rt->buf("vit_rnd").ensure((size_t)nkeep * T * sizeof(double)));
-    PS_TRY(rt->buf("vit_path").ensure((size_t)nkeep * T * sizeof(short)));
+    PS_TRY(rt->buf("vit_start").ensure(R * sizeof(int)));
+    PS_TRY(rt->buf("vit_rnd").ensure((size_t)nkeep * ttot * sizeof(double)));
+    PS_TRY(rt->buf("vit_path").ensure((size_t)nkeep * ttot * sizeof(short)));
     PS_TRY(rt->up(rt->buf("vit_att").p, att.data(), nkeep * sizeof(double)));
-    PS_HIP(hipMemcpyAsync(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * T * sizeof(double), hipMemcpyHostToDevice, rt->stream));
-    hipLaunchKernelGGL(k_vit_log, dim3((unsigned)(((size_t)T * NS + 255) / 256)), dim3(256), 0, rt->stream, d_fwd, (size_t)T * NS);
-    hipLaunchKernelGGL(k_vit_trace, dim3(nkeep), dim3(VT_THREADS), 0, rt->stream, d_fwd, T, start, skip, stay,
+    PS_TRY(rt->up(rt->buf("vit_start").p, starts.data(), R * sizeof(int)));
+    PS_HIP(hipMemcpyAsync(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * ttot * sizeof(double), hipMemcpyHostToDevice, rt->stream));
+    hipLaunchKernelGGL(k_vit_log, dim3((unsigned)(((size_t)ttot * NS + 255) / 256)), dim3(256), 0, rt->stream, d_fwd, (size_t)ttot * NS);
+    hipLaunchKernelGGL(k_vit_trace, dim3(nkeep, R), dim3(VT_THREADS), 0, rt->stream, d_regs, d_fwd, rt->buf("vit_start").as<int>(), skip, stay,
                        rt->buf("vit_att").as<double>(), rt->buf("vit_rnd").as<double>(), rt->buf("vit_path").as<short>());
     PS_HIP(hipGetLastError());
-    prof_end(rt, "viterbi", (double)T * NS * (8.0 * E + 8 + 2 + 8 + 8.0 * nkeep));
+    prof_end(rt, "viterbi", (double)ttot * NS * (8.0 * maxE + 8 + 2 + 8 + 8.0 * nkeep));
     short* hp = nullptr;
-    PS_TRY(rt->down(&hp, rt->buf("vit_path").p, (size_t)nkeep * T));
+    PS_TRY(rt->down(&hp, rt->buf("vit_path").p, (size_t)nkeep * ttot));
     PS_HIP(hipStreamSynchronize(rt->stream));
-    for (int k = 0; k < nkeep; k++) {
-        std::vector<int> p(T);
-        for (int i = 0; i < T; i++) p[i] = hp[(size_t)k * T + i];
-        paths->push_back(p);
+    for (int r = 0; r < R; r++) {
+        const int T = regions[r].T;
+        if (!T) continue;
+        const short* rp = hp + (size_t)nkeep * regs[r].t_off;
+        for (int k = 0; k < nkeep; k++) {
+            std::vector<int> p(T);
+            for (int i = 0; i < T; i++) p[i] = rp[(size_t)k * T + i];
+            (*paths)[r].push_back(p);
+        }
     }
     return PS_OK;
 }
