@@ -1,57 +1,91 @@
 #!/usr/bin/env python3
 """bench.py — kb of consensus refined per second at 10x coverage (BASELINE.json metric).
 
-One "step" = the full `poreseq consensus` schedule (Mutate('self') then up to 4 x {Mutate('viterbi'),
-Refine()}, poreseq/Mutate.py:70-85) over one BATCH of R independent synthetic regions, each 10 kb with 10
-event streams (BASELINE.json configs[1]), through the drop-in PSAlign API and the C ABI.  Regions are the
-reference's own unit of parallelism (one process per region file, README.md:48-54); a single region keeps
-only a few dozen of the 256 CUs busy, so one GPU refines R regions concurrently (default 16; one host thread
-with its own HIP stream(s), device pools and random stream per region).  With N GPUs every rank refines its own batch per step (weak scaling) and the value
-is the whole-job rate:  N * R * region_kb * K / max-over-ranks time.  The latency of one region processed
-alone is reported as well.
+One "step" = the full `poreseq consensus` schedule (Mutate('self') then up to 4 x {Mutate('viterbi'), Refine()},
+poreseq/Mutate.py:70-85) over one BATCH of R independent synthetic regions, each 10 kb with 10 event streams
+(BASELINE.json configs[1]), through the drop-in API and the C ABI.  Regions are the reference's own unit of
+parallelism (one process per region file, README.md:48-54).  One GPU refines the R regions of a step in LOCK-STEP from
+one host thread (poreseq_amd.batch / the ps_batch_* entry points): every phase of the schedule is one launch chain over
+all regions' events, with the default HIP environment (no extra hardware queues, no per-region threads or streams).
+The events of a step's regions are resident in HBM when the clock starts (RegionBatch.load: the marshalling + H2D copy
+a PSAlign call would do); DESIGN.md section 7 gives the PCIe-inclusive rate.  With N GPUs every rank refines its own
+batch per step (weak scaling, no data-path collective) and the value is the whole-job rate
+N * R * region_kb * K / max-over-ranks time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--length L] [--events E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--length L] [--events E] [--regions-per-gpu R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0, with the `roofline` of the dominant kernel (HIP-event time on the
-library's own stream in a separate profiled pass) and the `cpu_baseline` (the reference's C++ when
-oracle/_ref is built, else the oracle restatement) timed on a bounded sample.
+Prints ONE JSON line on rank 0 with
+  roofline        the dominant kernel class (HIP-event time on the library's stream in a separate profiled step of the
+                  same batch): algorithmic bytes per launch / average launch duration against the HBM peak; `traffic`
+                  from the committed rocprofv3 PMC measurement of the same command (profiles/, tools/pmc_bench.sh),
+                  refused when its launch shape disagrees with the live pass
+  north_star_1kb  1 kb / 10x: one region alone, a lock-step batch, and the reference C++ at the same size
+  cpu_baseline    the reference's C++ (oracle/_ref; the oracle restatement when that is not built) on the host cores:
+                  one thread, one process per core, and a same-size (10 kb) extrapolation from measured unit costs
 """
 import argparse
 import copy
 import json
 import os
 import sys
-import threading
 import time
-
-# concurrent regions need more than HIP's default 4 hardware queues; must be set before HIP initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-
-
-def _pre_hip_env(argv):
-    """Per-thread memory budget depends on how many regions share the GPU; read when the library first runs."""
-    R = 16
-    for k, a in enumerate(argv):
-        if a == "--regions-per-gpu" and k + 1 < len(argv):
-            R = int(argv[k + 1])
-        elif a.startswith("--regions-per-gpu="):
-            R = int(a.split("=", 1)[1])
-    # cap the DP-matrix bytes of one seed batch per host thread (R threads share one GPU's HBM)
-    os.environ.setdefault("PORESEQ_MAX_BATCH_GB", "8" if R <= 8 else "4")
-    # more than ~10 regions in flight: one HIP stream per region (second streams would oversubscribe the hardware
-    # queues; a region's Smith-Waterman batch then overlaps with other regions' work instead of its own realign)
-    if R > 10:
-        os.environ.setdefault("PORESEQ_ONE_STREAM", "1")
-
-
-_pre_hip_env(sys.argv)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_OF = {"fill": "k_fill", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}
+
+
+def _cpu_region_worker(job):
+    """one full consensus schedule on the CPU checker (own process: the reference is single-threaded)"""
+    length, events, seed, use_ref = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import backends as B
+    from poreseq_amd import synth
+    from poreseq_amd.consensus import consensus_region
+    from poreseq_amd.util import DEFAULT_PARAMS
+    params = dict(DEFAULT_PARAMS, verbose=0)
+    cls = B.RefPSAlign if use_ref else B.OraclePSAlign
+    sw = B.ref_swalign if use_ref else B.oracle_swalign
+    d, ev, _ = synth.make_region(length, events, seed, sw, params)
+    pa = B.make_pa(cls, d, ev, params)
+    B.reset_rand()
+    t = time.perf_counter()
+    consensus_region(pa, params)
+    return time.perf_counter() - t
+
+
+def _cpu_baseline_children(args):
+    """(1) one thread, full schedule, one region of --cpu-length bases; (2) one single-threaded process per core"""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import backends as B
+    use_ref = B.have_ref()
+    if not use_ref and not os.path.exists(B.ORACLE_SO):
+        return None
+    L, E = args.cpu_length, args.events
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        ct = pool.map(_cpu_region_worker, [(L, E, 1002, use_ref)])[0]
+        t1k = ct if L == 1000 else pool.map(_cpu_region_worker, [(1000, E, 5000, use_ref)])[0]
+    cpu = {"value": (L / 1000.0) / ct, "unit": "kb/s", "cores": 1, "kind": "reference" if use_ref else "port",
+           "sample": "full consensus schedule on one %d-base region, %d events, single thread (%.1f s)" % (L, E, ct),
+           "host_cores_available": os.cpu_count()}
+    nproc = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        with ctx.Pool(nproc) as pool:
+            pool.map(_cpu_region_worker, [(200, 5, 1, use_ref)] * nproc)      # start-up (imports) outside the clock
+            t = time.perf_counter()
+            pool.map(_cpu_region_worker, [(L, E, 3000 + k, use_ref) for k in range(nproc)], chunksize=1)
+            wall = time.perf_counter() - t
+        cpu["one_process_per_core"] = {"processes": nproc, "value": nproc * (L / 1000.0) / wall, "unit": "kb/s",
+                                       "sample": "%d regions of %d bases, one single-threaded process each, %.1f s wall" % (nproc, L, wall)}
+    except Exception as e:   # pragma: no cover
+        cpu["one_process_per_core"] = {"error": str(e)}
+    return {"cpu": cpu, "t1k": t1k, "use_ref": use_ref}
 
 
 def main():
@@ -61,16 +95,33 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--events", type=int, default=10)
-    ap.add_argument("--regions-per-gpu", type=int, default=16, help="independent regions refined concurrently on one GPU")
+    ap.add_argument("--regions-per-gpu", type=int, default=48, help="independent regions refined on one GPU per step")
+    ap.add_argument("--batches-in-flight", type=int, default=3,
+                    help="lock-step batches per GPU (one host thread each): while one batch is in a thin phase or on the host, "
+                         "the others keep the GPU full; the regions of a step are dealt round-robin to the batches")
     ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip everything that touches the CPU checkers (oracle / reference)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-region, 1 kb and profiled passes (profiling runs)")
     args = ap.parse_args()
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_env:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with python -m torch.distributed.run --nproc-per-node %d ...\n"
+                         % (args.gpus, world_env, args.gpus))
+        sys.exit(2)
+
+    # The CPU baseline runs in child processes (the reference is single-threaded; its only parallel mode is one process per
+    # region, README.md:48-54).  They are started HERE, before anything in this process touches the GPU.
+    cpu_pre = None
+    if world_env == 1 and not args.no_cpu:
+        cpu_pre = _cpu_baseline_children(args)
 
     from poreseq_amd import dist as psdist
     rank, local, world = psdist.init()
     import torch
     from poreseq_amd import _capi, synth
-    from poreseq_amd.consensus import consensus_region
+    from poreseq_amd.batch import RegionBatch
+    from poreseq_amd.consensus import consensus_region, consensus_regions
     from poreseq_amd.poreseqcpp import PSAlign, swalign
     from poreseq_amd.util import DEFAULT_PARAMS
 
@@ -79,127 +130,152 @@ def main():
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
 
-    def make(seed):
-        draft, events, truth = synth.make_region(args.length, args.events, seed, swalign, params)
-        return draft, events, truth
+    def make(seed, length=None):
+        return synth.make_region(length or args.length, args.events, seed, swalign, params)
 
-    def run(region):
-        draft, events, truth = region
+    def as_pa(region):
         pa = PSAlign()
-        pa.sequence, pa.events, pa.params = draft, copy.deepcopy(events), dict(params)
-        seq, _ = consensus_region(pa, params)
-        return seq, truth
+        pa.sequence, pa.events, pa.params = region[0], copy.deepcopy(region[1]), dict(params)
+        return pa
+
+    def run_batch(regs, timed=False, nb=1):
+        """one step: the regions dealt to `nb` lock-step batches, one host thread each; the clock (when timed) starts with
+        every batch's events resident in HBM"""
+        import threading
+        nb = max(1, min(nb, len(regs)))
+        groups = [regs[k::nb] for k in range(nb)]
+        pas = [[as_pa(r) for r in g] for g in groups]
+        rbs = [RegionBatch(p) for p in pas]
+        outs = [None] * nb
+        errs = []
+
+        def load(k):
+            try:
+                rbs[k].load()
+            except Exception as e:   # pragma: no cover
+                errs.append(e)
+
+        def work(k):
+            try:
+                outs[k] = consensus_regions(pas[k], params, batch=rbs[k])
+            except Exception as e:   # pragma: no cover
+                errs.append(e)
+
+        def fan(fn):
+            th = [threading.Thread(target=fn, args=(k,)) for k in range(1, nb)]
+            for t in th:
+                t.start()
+            fn(0)
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+
+        fan(load)           # each thread creates its own batch's AlignData: the library's runtimes are per host thread
+        if timed:
+            psdist.barrier()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fan(work)
+        if timed and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = [None] * len(regs)
+        for k in range(nb):
+            out[k::nb] = outs[k]
+        return dt, out
 
     # synthetic inputs for every step of this rank, generated outside the timed region
     R = max(1, args.regions_per_gpu)
     nsteps = args.warmup + args.steps
-    regions = [[make(1002 + 100000 * rank + 1000 * k + s) for s in range(nsteps)] for k in range(R)]
-    # ---- before any worker thread exists: one region alone (latency), then the profiled pass for the roofline ----
+    regions = [[make(1002 + 100000 * rank + 1000 * k + s) for k in range(R)] for s in range(nsteps)]
+
     pre = {}
-    if rank == 0:
-        run(regions[0][0])                      # warm: device pools
-        t1 = time.perf_counter()
-        run(regions[0][-1])
-        pre["single_region_s"] = time.perf_counter() - t1
+    if rank == 0 and not args.no_extras:
+        # ---- one region alone (latency) ----
+        run_batch(regions[0][:1])                      # warm: device pools, code objects
+        pre["single_region_s"] = run_batch(regions[-1][:1])[0]
+        # ---- north star comparison point: 1 kb / 10x ----
+        k1 = [make(5000 + k, 1000) for k in range(64)]
+        run_batch(k1[:1])
+        t1 = min(run_batch(k1[:1])[0] for _ in range(3))
+        run_batch(k1)
+        tb = run_batch(k1)[0]
+        pre["north_star_1kb"] = {"region_bases": 1000, "events": args.events, "single_region_s": t1,
+                                 "single_region_kb_s": 1.0 / t1, "lock_step_regions": len(k1),
+                                 "lock_step_kb_s": len(k1) * 1.0 / tb}
 
-        # ---- roofline of the dominant kernel: separate profiled pass (HIP events around each launch) ----
-        api.prof_reset()
-        api.prof_enable(True)
-        run(regions[0][-1])
-        api.prof_enable(False)
-        prof = {k: api.prof_get(k) for k in ("fill", "score", "sw", "viterbi")}
-        dom = max(prof, key=lambda k: prof[k][0])
-        ms, launches, nbytes = prof[dom]
-        achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-        kname = {"fill": "k_recur", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}[dom]
-        # HBM-side bytes per launch from the PMC counters cannot be collected from inside this process; they are
-        # measured offline with rocprofv3 on the same workload shape (tools/pmc_total.sh) and committed under profiles/
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_g_traffic_per_launch.json")) as fh:
-                tk = json.load(fh)["kernels"].get(kname)
-            if tk and args.length == 10000 and args.events == 10:
-                traffic = tk["fetch_bytes_per_launch"] + tk["write_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
-        pre["roofline"] = {"bound": "hbm", "kernel": kname,
-                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "traffic_source": "profiles/r01_g_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE + "
-                                                                  "WRITE_SIZE per launch, offline, same workload shape)" if traffic else None,
-                           "launches": launches, "avg_launch_ms": ms / max(launches, 1),
-                           "alg_bytes_per_launch": nbytes / max(launches, 1),
-                           "all_kernel_classes_ms": {k: v[0] for k, v in prof.items()}}
-
-    results = [None] * R
-    gate = threading.Barrier(R + 1)
-    errors = []
-
-    def worker(k):
-        try:
-            for s in range(args.warmup):
-                run(regions[k][s])
-            gate.wait()          # everyone is warm (device pools allocated)
-            gate.wait()          # the clock has started
-            for s in range(args.warmup, nsteps):
-                results[k] = run(regions[k][s])
-        except Exception as e:   # pragma: no cover
-            errors.append(e)
-            gate.abort()
-
-    threads = [threading.Thread(target=worker, args=(k,)) for k in range(R)]
-    for t in threads:
-        t.start()
-    gate.wait()
+    NB = max(1, args.batches_in_flight)
+    for s in range(args.warmup):
+        run_batch(regions[s], nb=NB)
+    dt = 0.0
+    last = None
+    for s in range(args.warmup, nsteps):
+        t, last = run_batch(regions[s], timed=True, nb=NB)
+        dt += t
     psdist.barrier()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gate.wait()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    psdist.barrier()
-    dt = psdist.max_over_ranks(time.perf_counter() - t0)
+    dt = psdist.max_over_ranks(dt)
     kb = args.length / 1000.0
     value = world * R * kb * args.steps / dt
-    accs = [results[0]]
 
     out = {
         "metric": "kb consensus refined/sec at 10x coverage", "value": value, "unit": "kb/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / max(args.steps, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "poreseq consensus, %d kb region, %dx synthetic coverage (BASELINE configs[1]), full "
-                               "Mutate.py schedule per region; a step is a batch of %d independent regions refined concurrently per GPU"
-                               % (args.length // 1000, args.events, R),
-                   "region_bases": args.length, "events": args.events, "regions_per_gpu": R,
-                   "parallelism": "%d regions x %d GPU(s), no data-path collective" % (R, world)},
+        "config": {"workload": "poreseq consensus, %d kb region, %dx synthetic coverage (BASELINE configs[1]), full Mutate.py "
+                               "schedule per region; a step is %d independent regions per GPU, refined as %d lock-step batches "
+                               "(events resident in HBM when the clock starts)" % (args.length // 1000, args.events, R, NB),
+                   "region_bases": args.length, "events": args.events, "regions_per_gpu": R, "batches_in_flight": NB,
+                   "parallelism": "%d regions x %d GPU(s), %d host thread(s) per GPU, no data-path collective" % (R, world, NB)},
     }
 
     if rank == 0:
-        # accuracy of the refined consensus (trimmed by end_trim) against the synthetic truth
-        a0 = swalign(regions[0][-1][0], regions[0][-1][2])[0]
-        a1 = swalign(accs[-1][0], accs[-1][1])[0]
+        a0 = swalign(regions[-1][0][0], regions[-1][0][2])[0]
+        a1 = swalign(last[0][0], regions[-1][0][2])[0]
         out["accuracy"] = {"draft_percent": a0, "consensus_percent": a1}
         out.update(pre)
-        # all regions in flight together: HBM-side bytes of one whole schedule (offline PMC sums) x regions per second
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_g_traffic_per_launch.json")) as fh:
-                ws = json.load(fh)["whole_schedule"]
-            if args.length == 10000 and args.events == 10 and "roofline" in out:
-                gbs = (ws["fetch_bytes"] + ws["write_bytes"]) / 1e9 * (value / kb) / world
-                out["roofline"]["aggregate_hbm_gbs_per_gpu"] = gbs
-                out["roofline"]["aggregate_hbm_frac"] = gbs / HBM_PEAK_GBS
-        except (OSError, ValueError, KeyError):
-            pass
 
-        # ---- parity spot-check + CPU baseline (oracle / reference: checker and baseline only) ----
-        if world == 1:
+        if not args.no_extras:
+            # ---- roofline of the dominant kernel class: a separate profiled step of the same batch (HIP events per launch) ----
+            api.prof_reset()
+            api.prof_enable(True)
+            run_batch(regions[-1][:max(1, R // NB)])   # one lock-step batch of the size the timed steps use
+            api.prof_enable(False)
+            prof = {k: api.prof_get(k) for k in KERNEL_OF}
+            dom = max(prof, key=lambda k: prof[k][0])
+            ms, launches, nbytes = prof[dom]
+            achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                    "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": nbytes / max(launches, 1),
+                    "sweeps_per_launch": api.prof_units(dom) / max(launches, 1) if dom == "fill" else None,
+                    "all_kernel_classes_ms": {k: v[0] for k, v in prof.items()}}
+            # HBM-side bytes per launch cannot be collected from inside this process: rocprofv3 --pmc on this very command
+            # (tools/pmc_bench.sh) writes profiles/r02_traffic.json; it is used only if its launch shape matches the live pass
+            try:
+                with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+                    tj = json.load(fh)
+                tk = tj["kernels"].get(KERNEL_OF[dom])
+                same = (tk and tj.get("length") == args.length and tj.get("events") == args.events and tj.get("regions_per_batch") == max(1, R // NB)
+                        and abs(tk["alg_bytes_per_launch"] / roof["alg_bytes_per_launch"] - 1.0) < 0.05)
+                if same:
+                    roof["traffic"] = tk["fetch_bytes_per_launch"] + tk["write_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r02_traffic.json: " + tj.get("source", "")
+                    roof["schedule_traffic_gb_per_region"] = tj.get("whole_schedule", {}).get("gb_per_region")
+                else:
+                    roof["traffic_source"] = "profiles/r02_traffic.json ignored: measured on a different launch shape"
+            except (OSError, ValueError, KeyError, ZeroDivisionError):
+                pass
+            out["roofline"] = roof
+            nprof = max(1, R // NB)
+            sched = {"fill_sweeps": api.prof_units("fill") * R / nprof, "score_items": api.prof_units("score") * R / nprof}
+
+        # ---- parity spot-check + CPU baseline (oracle / reference: checker and baseline only, never the thing measured) ----
+        if cpu_pre is not None:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import backends as B
-            use_ref = B.have_ref()
+            use_ref = cpu_pre["use_ref"]
             cls = B.RefPSAlign if use_ref else B.OraclePSAlign
             cpu_sw = B.ref_swalign if use_ref else B.oracle_swalign
             d, ev, tr = synth.make_region(400, 6, 77, cpu_sw, params)
@@ -207,23 +283,32 @@ def main():
             c = B.make_pa(cls, d, copy.deepcopy(ev), params).ScoreEvents()
             gp = B.make_pa(PSAlign, d, copy.deepcopy(ev), params).ScorePoints()
             cp = B.make_pa(cls, d, copy.deepcopy(ev), params).ScorePoints()
-            rel = max([abs(x - y) / max(abs(y), 1e-300) for x, y in zip(g, c)] +
-                      [abs(x.score - y.score) / abs(y.score) for x, y in zip(gp, cp) if abs(y.score) > 1e-3])
-            out["logl_max_rel_err_vs_cpu"] = rel
-            if not args.no_cpu:
-                d, ev, tr = synth.make_region(args.cpu_length, args.events, 1002, cpu_sw, params)
+            out["logl_max_rel_err_vs_cpu"] = max([abs(x - y) / max(abs(y), 1e-300) for x, y in zip(g, c)] +
+                                                 [abs(x.score - y.score) / abs(y.score) for x, y in zip(gp, cp) if abs(y.score) > 1e-3])
+            cpu = cpu_pre["cpu"]
+            # the SAME size as the GPU workload: measured unit costs at this size, times the unit counts of the GPU's own schedule
+            if not args.no_extras:
+                import numpy as np
+                d, ev, tr = regions[-1][0]
                 pa = B.make_pa(cls, d, copy.deepcopy(ev), params)
-                B.reset_rand()
-                t = time.perf_counter()
-                consensus_region(pa, params)
-                ct = time.perf_counter() - t
-                out["cpu_baseline"] = {
-                    "value": (args.cpu_length / 1000.0) / ct, "unit": "kb/s", "cores": 1,
-                    "kind": "reference" if use_ref else "port",
-                    "sample": "full consensus schedule on one %d-base region, %d events, single thread (%.1f s); the "
-                              "reference is O(L^2) per region, so its 10 kb rate is ~5x lower per kb (BASELINE.md 2a)"
-                              % (args.cpu_length, args.events, ct),
-                    "host_cores_available": os.cpu_count()}
+                t = time.perf_counter(); pa.ScoreEvents(); t_fill = (time.perf_counter() - t) / len(ev)
+                muts = synth.random_point_mutations(np.random.default_rng(5), d, 3000)
+                pw = dict(params, scoring_width=params["point_width"])
+                t = time.perf_counter(); B.make_pa(cls, d, copy.deepcopy(ev), pw).ScoreMutations(muts)
+                t_item = max(time.perf_counter() - t - 2 * len(ev) * t_fill, 0.0) / (len(muts) * len(ev))
+                est = (sched["fill_sweeps"] * t_fill + sched["score_items"] * t_item) / R
+                cpu["same_size"] = {"region_bases": args.length, "seconds_per_sweep": t_fill, "seconds_per_scored_item": t_item,
+                                    "sweeps_per_region": sched["fill_sweeps"] / R, "scored_items_per_region": sched["score_items"] / R,
+                                    "extrapolated_seconds_per_region": est, "value": kb / est, "unit": "kb/s",
+                                    "note": "banded fills and edit scoring only (Smith-Waterman, Viterbi and list handling left out: a lower "
+                                            "bound on the reference's time); unit costs measured on one core at this size, unit counts "
+                                            "taken from the GPU run's own schedule"}
+                if "north_star_1kb" in out:
+                    ns = out["north_star_1kb"]
+                    ns["cpu_reference_s"] = cpu_pre["t1k"]
+                    ns["speedup_single_region"] = cpu_pre["t1k"] / ns["single_region_s"]
+                    ns["speedup_lock_step"] = ns["lock_step_kb_s"] * cpu_pre["t1k"]
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
 

@@ -73,6 +73,12 @@ int ps_align_create(ps_align** out, const char* seq, int64_t seq_len, int32_t n_
 void ps_align_destroy(ps_align* a);
 /* `data.params.scoring_width = params['point_width']` (_poreseqcpp.pyx:293-294, 361-362, 465-466). */
 int ps_align_set_scoring_width(ps_align* a, int32_t width);
+/* A driver that keeps one AlignData alive across several PSAlign calls (events resident in device memory instead of
+ * re-marshalled per call) announces each new call with this: it resets what PythonToAlignData would have rebuilt —
+ * params.scoring_width and the seed-likelihood cache (cpp/AlignData.h:34), which the reference drops between PSAlign
+ * calls (_poreseqcpp.pyx:139-153).  Sequence and events' ref_align / ref_like carry over, exactly as the Python
+ * attributes do in the reference. */
+int ps_align_new_call(ps_align* a, int32_t scoring_width);
 int32_t ps_align_n_events(const ps_align* a);
 int64_t ps_align_n_levels(const ps_align* a, int32_t ev);
 int64_t ps_align_sequence_length(const ps_align* a);
@@ -181,6 +187,8 @@ int ps_debug_fill(ps_align* a, int32_t ev, int32_t direction, double* main, doub
 int ps_prof_enable(int32_t on);
 int ps_prof_reset(void);
 int ps_prof_get(const char* name, double* ms, int64_t* launches, double* alg_bytes);
+/* work units of the class since reset: "fill" = sweeps (one alignment, one direction), "score" = (event, edit) items */
+int ps_prof_units(const char* name, double* units);
 
 #ifdef __cplusplus
 }

@@ -763,6 +763,7 @@ int ps_align_create(ps_align** out, const char* seq, int64_t seq_len, int32_t n_
 }
 void ps_align_destroy(ps_align* a) { delete a; }
 int ps_align_set_scoring_width(ps_align* a, int32_t w) { if (!a) return fail(PS_ERR_BAD_ARG, "null"); a->d.par.scoring_width = w; return PS_OK; }
+int ps_align_new_call(ps_align* a, int32_t w) { if (!a) return fail(PS_ERR_BAD_ARG, "null"); a->d.par.scoring_width = w; a->d.seqlikes.clear(); return PS_OK; }
 int32_t ps_align_n_events(const ps_align* a) { return a ? (int32_t)a->d.ev.size() : 0; }
 int64_t ps_align_n_levels(const ps_align* a, int32_t e) { return (a && e >= 0 && e < (int)a->d.ev.size()) ? a->d.ev[e].n : -1; }
 int64_t ps_align_sequence_length(const ps_align* a) { return a ? (int64_t)a->d.seq.bases.size() : -1; }
@@ -920,6 +921,7 @@ int ps_rand_draw(int64_t n, double* out) { for (int64_t k = 0; k < n; k++) out[k
 int ps_prof_enable(int32_t) { return PS_OK; }
 int ps_prof_reset(void) { return PS_OK; }
 int ps_prof_get(const char*, double* ms, int64_t* n, double* b) { if (ms) *ms = 0; if (n) *n = 0; if (b) *b = 0; return PS_OK; }
+int ps_prof_units(const char*, double* u) { if (u) *u = 0; return PS_OK; }
 
 }  // extern "C"
 

@@ -38,6 +38,7 @@ SYMBOLS = {
                                   C.POINTER(PsParams)]),
     "ps_align_destroy": (None, [C.c_void_p]),
     "ps_align_set_scoring_width": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ps_align_new_call": (C.c_int, [C.c_void_p, C.c_int32]),
     "ps_align_n_events": (C.c_int32, [C.c_void_p]),
     "ps_align_n_levels": (C.c_int64, [C.c_void_p, C.c_int32]),
     "ps_align_sequence_length": (C.c_int64, [C.c_void_p]),
@@ -79,6 +80,7 @@ SYMBOLS = {
     "ps_prof_enable": (C.c_int, [C.c_int32]),
     "ps_prof_reset": (C.c_int, []),
     "ps_prof_get": (C.c_int, [C.c_char_p, c_dp, c_i64p, c_dp]),
+    "ps_prof_units": (C.c_int, [C.c_char_p, c_dp]),
 }
 
 
@@ -367,6 +369,11 @@ class CApi:
 
     def prof_reset(self):
         self.check(self.lib.ps_prof_reset())
+
+    def prof_units(self, name):
+        u = C.c_double(0)
+        self.check(self.lib.ps_prof_units(name.encode(), C.byref(u)))
+        return float(u.value)
 
     def prof_get(self, name):
         ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)

@@ -17,12 +17,40 @@ from . import poreseqcpp
 class RegionBatch:
     """A set of PSAlign objects (independent regions) refined in lock-step.  All methods work in place on the members."""
 
-    def __init__(self, pas, api=None):
+    def __init__(self, pas, api=None, resident=True):
+        """resident=True keeps one native AlignData per region for the life of the batch: the events are marshalled and
+        copied to the GPU once, every later call only announces itself (`ps_align_new_call` resets the scoring width and
+        the seed-likelihood cache, the two things a fresh AlignData would differ in), and sequence / ref_align / ref_like
+        are written back to the Python objects when the batch is closed (or by `sync()`).  resident=False rebuilds the
+        AlignData for every call, as PythonToAlignData does (pyx:139-153); results are identical."""
         self.pas = list(pas)
         self.api = api if api is not None else (self.pas[0]._native() if self.pas else poreseqcpp._api())
         self.rngs = [self.api.rng_create(1) for _ in self.pas]   # rand() of a fresh process per region (Viterbi.cpp:108)
+        self.resident = bool(resident)
+        self._h = {}
+
+    def load(self, idx=None):
+        """Create the resident AlignData of the regions `idx` now (e.g. before a timed section)."""
+        for i in (range(len(self.pas)) if idx is None else idx):
+            if self.resident and i not in self._h:
+                pa = self.pas[i]
+                self._h[i] = self.api.align_create(pa.sequence, pa.events, pa.params)
+        return self
+
+    def sync(self, idx=None):
+        """Write sequence / ref_align / ref_like of resident regions back to their PSAlign objects."""
+        for i in (list(self._h) if idx is None else idx):
+            h = self._h.get(i)
+            if h is not None:
+                pa = self.pas[i]
+                pa.sequence = self.api.align_sequence(h)
+                self.api.align_update_events(h, pa.events)
 
     def close(self):
+        self.sync()
+        for h in self._h.values():
+            self.api.align_destroy(h)
+        self._h = {}
         for r in self.rngs:
             self.api.rng_destroy(r)
         self.rngs = []
@@ -40,14 +68,24 @@ class RegionBatch:
         hs = []
         for i in idx:
             pa = self.pas[i]
-            h = self.api.align_create(pa.sequence, pa.events, pa.params)
-            if point_width and 'point_width' in pa.params:
-                self.api.check(self.api.lib.ps_align_set_scoring_width(h, int(pa.params['point_width'])))
+            if self.resident:
+                self.load([i])
+                h = self._h[i]
+                w = pa.params['point_width'] if (point_width and 'point_width' in pa.params) else pa.params.get('scoring_width', 150)
+                self.api.check(self.api.lib.ps_align_new_call(h, int(w)))
+            else:
+                h = self.api.align_create(pa.sequence, pa.events, pa.params)
+                if point_width and 'point_width' in pa.params:
+                    self.api.check(self.api.lib.ps_align_set_scoring_width(h, int(pa.params['point_width'])))
             hs.append(h)
         return hs
 
     def _close(self, idx, hs, write_back=True):
         for i, h in zip(idx, hs):
+            if self.resident:
+                if write_back:
+                    self.pas[i].sequence = self.api.align_sequence(h)   # cheap; refs follow at sync() / close()
+                continue
             if write_back:
                 pa = self.pas[i]
                 pa.sequence = self.api.align_sequence(h)

@@ -61,12 +61,13 @@ def consensus_region(pa, params=None, reps=4, verbose=0, refseq=None, log=None):
     return (pa.sequence, acc)
 
 
-def consensus_regions(pas, params=None, reps=4, refseqs=None, logs=None):
+def consensus_regions(pas, params=None, reps=4, refseqs=None, logs=None, batch=None, resident=True):
     """The consensus schedule of `consensus_region` for several independent regions in lock-step (poreseq_amd.batch):
     every PSAlign call of the schedule is issued once for all regions that still take part in it, so each phase is one
     launch chain on the GPU.  Returns [(sequence, accuracy)] in the order of `pas`; each entry equals what
     `consensus_region(pa)` returns for that region run on its own from a fresh process.
     `logs`, when given, is a list of lists receiving (call, nbases, sequence) per region after every call.
+    `batch`: an already loaded RegionBatch over `pas` (events resident on the GPU, see RegionBatch.load); it is closed here.
     """
     from .batch import RegionBatch
     n = len(pas)
@@ -84,7 +85,7 @@ def consensus_regions(pas, params=None, reps=4, refseqs=None, logs=None):
         def note(i, call, nb):
             if logs is not None:
                 logs[i].append((call, nb, pas[i].sequence))
-        with RegionBatch(pas) as rb:
+        with (batch if batch is not None else RegionBatch(pas, resident=resident)) as rb:
             tot = rb.Mutate(todo, reps=reps)
             for i in todo:
                 note(i, "Mutate:self", tot[i])

@@ -42,6 +42,12 @@ int ps_align_set_scoring_width(ps_align* a, int32_t w) {
     a->a.par.scoring_width = w;
     return PS_OK;
 }
+int ps_align_new_call(ps_align* a, int32_t w) {
+    if (!a) return fail(PS_ERR_BAD_ARG, "null handle");
+    a->a.par.scoring_width = w;
+    a->a.seqlikes.clear();
+    return PS_OK;
+}
 int32_t ps_align_n_events(const ps_align* a) { return a ? a->a.E : 0; }
 int64_t ps_align_n_levels(const ps_align* a, int32_t e) { return (a && e >= 0 && e < a->a.E) ? a->a.n[e] : -1; }
 int64_t ps_align_sequence_length(const ps_align* a) { return a ? (int64_t)a->a.bases.size() : -1; }
@@ -312,6 +318,14 @@ int ps_prof_get(const char* name, double* ms, int64_t* n, double* bytes) {
     if (ms) *ms = p.ms;
     if (n) *n = p.launches;
     if (bytes) *bytes = p.bytes;
+    return PS_OK;
+}
+
+int ps_prof_units(const char* name, double* units) {
+    NEED_RT();
+    Prof p;
+    if (name) { auto it = rt->prof.find(name); if (it != rt->prof.end()) p = it->second; }
+    if (units) *units = p.units;
     return PS_OK;
 }
 

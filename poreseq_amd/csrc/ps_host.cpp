@@ -472,7 +472,7 @@ int realign(Runtime* rt, Batch& b) {
     // nine slots more than the widest footprint: a lane idles at least nine anti-diagonals between two rows, so a prefetch
     // window of k_fill (fetched six steps ahead, four steps long) never spans two rows of a lane that has a cell
     PS_TRY(b.place(rt, std::max(*w, 1) + 9));
-    if (rt->prof_on) rt->prof["fill"].bytes += b.fill_alg_bytes();
+    if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs * b.ndir; }
     PS_TRY(launch_fill(rt, b.d, b.jobs, b.ndir, b.maxS, b.P, b.ncols));
     PS_TRY(launch_backtrace(rt, b.d, b.maxn));
     PS_TRY(launch_updaterefs(rt, b.d));
@@ -726,6 +726,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
             const double kk = (double)p.M / std::max(p.nr0, 1);
             for (int i = 0; i < p.M; i++) t += 16 * (Bs + 1) + 16 * Br + 24 * (Bs + p.mlen[i] + 6) + 32 * Br / kk + 8;
             rt->prof["score"].bytes += t * as[k]->E;
+            rt->prof["score"].units += (double)p.M * as[k]->E;
         }
         PS_TRY(launch_score(rt, b.d, sas[k], cls_items[k].data(), cls_count[k].data()));
         PS_TRY(rt->down(&sc[k], sas[k].score, (size_t)p.M));

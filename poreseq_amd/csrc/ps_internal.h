@@ -72,7 +72,7 @@ struct Stage {
     void release(size_t m) { if (m != (size_t)-1 && chunks.size() <= 1) used = m; }
 };
 
-struct Prof { double ms = 0; int64_t launches = 0; double bytes = 0; };
+struct Prof { double ms = 0; int64_t launches = 0; double bytes = 0; double units = 0; };
 
 struct Runtime {
     bool ready = false;

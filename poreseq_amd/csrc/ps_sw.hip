@@ -112,8 +112,11 @@ __device__ __forceinline__ unsigned sw_row(int (&G)[K], const int (&c2)[K], cons
 constexpr int SW_SPIN_LIMIT = 1 << 22;
 template <int K>
 __global__ __launch_bounds__(64 * SWW) void k_sw_fill(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
-                                                  int* blkmax, int* prog) {
-    const int ss = blockIdx.x;
+                                                  int* blkmax, int* prog, int* ticket, int* res) {
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ticket[blockIdx.y], 1);
+    __syncthreads();
+    const int ss = s_ticket;
     const SwPair p = pairs[blockIdx.y];
     if (p.n1 <= 0 || p.n2 <= 0 || ss * SWW * 64 * K >= p.n2) return;
     int* prog_my = prog + (int64_t)blockIdx.y * gridDim.x + ss;
@@ -145,10 +148,12 @@ __global__ __launch_bounds__(64 * SWW) void k_sw_fill(const SwPair* pairs, const
         const int i0 = c * SWB;
         if (w == 0 && ss > 0 && c >= 0 && c < nchunks) {   // wave-uniform: the rows of this chunk must have been published
             const int need = min(p.n1, (i0 + SWB + 63) & ~63);
-            for (int spins = 0; seen < need && spins < SW_SPIN_LIMIT; spins++) {
+            int spins = 0;
+            for (; seen < need && spins < SW_SPIN_LIMIT; spins++) {
                 seen = __hip_atomic_load(prog_my - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (seen < need) __builtin_amdgcn_s_sleep(8);
             }
+            if (seen < need && l == 0) atomicOr(&res[p.res_off + 5], 1);   // gave up waiting: the pair's result is not valid
         }
         if (wave_on && c >= 0 && c < nchunks && l < SWB && i0 + l < p.n1) {
             ch = (int)(unsigned char)s1[i0 + l] << 4;
@@ -303,8 +308,8 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const char
 
 template <int K>
 static int sw_run(Runtime* rt, hipStream_t st, int np, int nss, const SwPair* d_pairs, const char* d_chars, int* d_row, int* d_col,
-                  int* d_blk, int* d_prog, int* d_out, int* d_res) {
-    hipLaunchKernelGGL(k_sw_fill<K>, dim3(nss, np), dim3(64 * SWW), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_prog);
+                  int* d_blk, int* d_prog, int* d_ticket, int* d_out, int* d_res) {
+    hipLaunchKernelGGL(k_sw_fill<K>, dim3(nss, np), dim3(64 * SWW), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_res);
     PS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_sw_trace<K>, dim3(np), dim3(64), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res);
     PS_HIP(hipGetLastError());
@@ -349,7 +354,7 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     PS_TRY(rt->buf("sw_row").ensure(row_tot * sizeof(int)));
     PS_TRY(rt->buf("sw_col").ensure(col_tot * sizeof(int)));
     PS_TRY(rt->buf("sw_blk").ensure(blk_tot * sizeof(int)));
-    PS_TRY(rt->buf("sw_prog").ensure((size_t)np * nss * sizeof(int)));
+    PS_TRY(rt->buf("sw_prog").ensure((size_t)np * (nss + 1) * sizeof(int)));   // progress per strip + one ticket counter per pair
     PS_TRY(rt->buf("sw_out").ensure(out_tot * sizeof(int)));
     PS_TRY(rt->buf("sw_res").ensure((size_t)np * 8 * sizeof(int)));
     SwPair* d_pairs = rt->buf("sw_pairs").as<SwPair>();
@@ -358,6 +363,7 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     int* d_col = rt->buf("sw_col").as<int>();
     int* d_blk = rt->buf("sw_blk").as<int>();
     int* d_prog = rt->buf("sw_prog").as<int>();
+    int* d_ticket = d_prog + (size_t)np * nss;
     int* d_out = rt->buf("sw_out").as<int>();
     int* d_res = rt->buf("sw_res").as<int>();
     hipStream_t st = nullptr;
@@ -367,11 +373,11 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     PS_TRY(rt->up(d_chars, pool.data(), pool.size(), st));
     PS_HIP(hipMemsetAsync(d_res, 0, (size_t)np * 8 * sizeof(int), st));
     PS_HIP(hipMemsetAsync(d_blk, 0, blk_tot * sizeof(int), st));   // waves beyond a pair's last column never write theirs
-    PS_HIP(hipMemsetAsync(d_prog, 0, (size_t)np * nss * sizeof(int), st));
+    PS_HIP(hipMemsetAsync(d_prog, 0, (size_t)np * (nss + 1) * sizeof(int), st));
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw0, st));
     switch (K) {
-        case 4: PS_TRY(sw_run<4>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_out, d_res)); break;
-        default: PS_TRY(sw_run<8>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_out, d_res)); break;
+        case 4: PS_TRY(sw_run<4>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res)); break;
+        default: PS_TRY(sw_run<8>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res)); break;
     }
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw1, st));
     PS_TRY(rt->hbuf("sw_res").ensure((size_t)np * 8 * sizeof(int)));
@@ -395,6 +401,8 @@ int sw_finish(Runtime* rt, SwJob* job, std::vector<SwResult>* out) {
             pr.ms += ms; pr.launches += 1; pr.bytes += job->cells * 5.0;  // 4-byte score + 1-byte step per cell (the reference's footprint)
         }
     }
+    for (int k = 0; k < np; k++)
+        if (job->res[k * 8 + 5]) return fail(PS_ERR_HIP, "Smith-Waterman: a strip gave up waiting for its left neighbour (result discarded)");
     for (int k = 0; k < np; k++) {
         const int n = job->res[k * 8 + 3], nm = job->res[k * 8 + 4];
         const SwPair& p = job->pairs[k];
