@@ -251,6 +251,16 @@ typedef v4i __attribute__((aligned(4))) v4i_a4;   // four states at any 4-byte a
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// a value every lane of the wave agrees on, moved to scalar registers (pointers and sizes read through the job table arrive in
+// vector registers; addressing with them would cost 64-bit vector arithmetic per access)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (T*)(((uint64_t)hi << 32) | lo);
+}
+
 template <int DIR>
 struct FillState {
     double cm, cs;         // this lane's latest main / stay; -infinity while it has no cell
@@ -262,7 +272,6 @@ struct FillState {
     int stw[2][4];         // state windows (two groups in flight)
     double lv[2][4];       // level windows {level mean, level stdv, 3 log stdv, 1 / level stdv}
     double mr[8];          // model row of the lane's column on anti-diagonal s + 2 (read from LDS one step earlier)
-    unsigned ringat;       // byte offset of the lane's column in the column-maxima ring
 };
 
 struct FillCtx {
@@ -308,7 +317,9 @@ __device__ __forceinline__ double fill_emission(const FillCtx& c, const double (
 __device__ __forceinline__ void fill_model_row(const FillCtx& c, int state, double (&m)[8]) {
     // rows are 80 bytes apart: with 64 the k-th quarter of every row falls on 4 of the 16 four-bank groups (ds_read_b128 of 64
     // random rows: 71 % conflict cycles measured), with 80 on all 16
-    const char* row = c.mdl + (state < 0 ? 0 : state) * MODEL_ROW_BYTES;
+    static_assert(MODEL_ROW_BYTES == 80, "row address below is state * 64 + state * 16");
+    const int st0 = state < 0 ? 0 : state;
+    const char* row = c.mdl + ((st0 << 6) + (st0 << 4));
     const double2 a = *(const double2*)row, bq = *(const double2*)(row + 16), cq = *(const double2*)(row + 32), dq = *(const double2*)(row + 48);
     m[0] = a.x; m[1] = a.y; m[2] = bq.x; m[3] = bq.y; m[4] = cq.x; m[5] = cq.y; m[6] = dq.x; m[7] = dq.y;
 }
@@ -351,7 +362,6 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
         const bool behind = lo_s >= 0 && i < lo_s;
         if (!SLOW) i = behind ? i + c.P : i;     // lo moves one row per step at most: one slot's row falls out of [lo, lo + P)
         else if (behind) i = fill_row_of(c, lo_s);
-        if (behind) r.ringat = (unsigned)((s - i) * 8) & c.ringmask;
         r.row = i;
     }
     const bool inb = lo_s >= 0 && i <= hi_s;
@@ -456,8 +466,7 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
             *(double*)q = r.cm; *(double*)(q + 8) = r.cs + o; *(double*)(q + 16) = r.cm + o;
         }
         // column maximum (scores are >= 0: their bit patterns order like unsigned integers; 0 is a no-op)
-        atomicMax((unsigned long long*)(c.ring + r.ringat), (unsigned long long)__double_as_longlong(rx));
-        r.ringat = (r.ringat + 8) & c.ringmask;
+        atomicMax((unsigned long long*)(c.ring + (((unsigned)(s - i) << 3) & c.ringmask)), (unsigned long long)__double_as_longlong(rx));
         r.dm = um; r.de = ue;
         r.pin = inb; r.ptop = top; r.pdead = dead;
     }
@@ -487,13 +496,13 @@ constexpr int FILL_MODEL_BYTES = MODEL_ROW_BYTES * NS;
 template <int DIR, bool FASTDIV>
 __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const char* model, char* hsm, const int slot, const int Smax,
                                           const int rcols, const int slowwords) {
-    const int P = J.P;
+    const int P = uni(J.P);
     FillCtx c;
-    c.lev = (PS_GLOBAL const v4d*)J.lev[DIR]; c.st = (gcip)J.st;
-    c.LO = (gcip)(b.lo + J.lo_off[DIR]); c.HI = (gcip)(b.hi + J.lo_off[DIR]);
-    c.rec = (PS_GLOBAL char*)(b.rec + J.mat_off[DIR] - (int64_t)MAT_FRONT * P); c.flg = (PS_GLOBAL char*)(b.flg + J.mat_off[DIR] - (int64_t)MAT_FRONT * P);
+    c.lev = (PS_GLOBAL const v4d*)uni_ptr(J.lev[DIR]); c.st = (gcip)uni_ptr(J.st);
+    c.LO = (gcip)uni_ptr(b.lo + J.lo_off[DIR]); c.HI = (gcip)uni_ptr(b.hi + J.lo_off[DIR]);
+    c.rec = (PS_GLOBAL char*)uni_ptr(b.rec + J.mat_off[DIR] - (int64_t)MAT_FRONT * P); c.flg = (PS_GLOBAL char*)uni_ptr(b.flg + J.mat_off[DIR] - (int64_t)MAT_FRONT * P);
     c.rec_off = (unsigned)slot * 16u; c.flg_off = (unsigned)slot * 2u;
-    c.P = P; c.n0 = J.n0; c.C = J.C; c.slot = slot;
+    c.P = P; c.n0 = uni(J.n0); c.C = uni(J.C); c.slot = slot;
     c.lsk = J.lsk; c.lst = J.lst; c.lex = J.lex; c.lin = J.lin; c.off = J.lik_offset; c.log2pi = b.log2pi;
     constexpr int RB = DIR ? 24 : 16;   // bytes per exchanged record: {main, stay} / {main, stay + em, main + em}
     c.mdl = model;
@@ -512,7 +521,7 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const 
         *(double*)(c.xch + c.wa[k]) = NINF; *(double*)(c.xch + c.wa[k] + 8) = NINF;
         if (DIR) *(double*)(c.xch + c.wa[k] + 16) = NINF;
     }
-    const int S = (int)J.S;                              // this half's sweep; the loops below run to Smax >= S (idle steps past S)
+    const int S = uni((int)J.S);                         // this half's sweep; the loops below run to Smax >= S (idle steps past S)
     const int s_first = 2 - FB;                          // the pipeline needs a few steps to fill; they fall into the front padding
     c.S = S;
     __syncthreads();
@@ -528,7 +537,6 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const 
     r.cm = NINF; r.cs = NINF; r.dm = NINF; r.de = NINF; r.o1 = 0.0; r.o2 = 0.0;
     r.pin = false; r.ptop = false; r.pdead = false;
     r.row = slot == 0 ? P : slot;   // rows start at 1: the smallest row of this slot's residue class
-    r.ringat = (unsigned)((s_first - r.row) * 8) & c.ringmask;
 #pragma unroll
     for (int k = 0; k < 4; k++) r.stq[k] = 0;
 #pragma unroll
