@@ -237,10 +237,10 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
         const Align* a = s.a;
         const int W = a->par.realign_width;
         if (W < 0) return fail(PS_ERR_BAD_ARG, "realign_width < 0");
-        // widest possible footprint 2W + 1, plus the idle slots k_fill wants between two rows of a lane
+        // widest possible footprint 2W + 1, plus the idle slots k_fill wants between two rows of a lane; the slots actually
+        // used follow the measured footprint (realign), typically (2W + 1) / (1 + levels per base) + 9
         const int pm = std::max(64, ((2 * W + 10 + 63) / 64) * 64);
-        if (pm > 1024) return fail(PS_ERR_UNSUPPORTED, "realign_width > 507: band wider than one workgroup");
-        Pmax = std::max(Pmax, pm);
+        Pmax = std::max(Pmax, std::min(pm, 1024));
         JobD j;
         memset(&j, 0, sizeof(j));
         j.mean = a->d_mean + a->off[s.ev]; j.stdv = a->d_stdv + a->off[s.ev]; j.lsd = a->d_lsd + a->off[s.ev];
@@ -471,6 +471,9 @@ int realign(Runtime* rt, Batch& b) {
     PS_HIP(hipStreamSynchronize(rt->stream));
     // nine slots more than the widest footprint: a lane idles at least nine anti-diagonals between two rows, so a prefetch
     // window of k_fill (fetched six steps ahead, four steps long) never spans two rows of a lane that has a cell
+    if (std::max(*w, 1) + 9 > 1024)
+        return fail(PS_ERR_UNSUPPORTED, "band footprint of " + std::to_string(*w) + " rows on one anti-diagonal: wider than one workgroup (1015); "
+                                        "realign_width up to ~980 fits for events with about one level per base");
     PS_TRY(b.place(rt, std::max(*w, 1) + 9));
     if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs * b.ndir; }
     PS_TRY(launch_fill(rt, b.d, b.jobs, b.ndir, b.maxS, b.P, b.ncols));

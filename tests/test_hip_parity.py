@@ -146,6 +146,33 @@ def test_viterbi_seeds_match_oracle():
         assert out[0] == out[1], nkeep
 
 
+def test_viterbi_stochastic_seeds_sweep():
+    """60 (region, generator seed) pairs x 16 stochastic back-traces each: the forward weights of ViterbiMutate are computed with
+    device exp / log and tree sums (a few ulp from the reference's serial sums, ps_viterbi.hip), so a back-trace could in
+    principle flip where a deviate lands within an ulp of a boundary.  Every one of the 960 seed sequences must equal the oracle's."""
+    import ctypes
+    rng = np.random.default_rng(2024)
+    hip, orc = _capi.load_hip(), B.oracle_api()
+    libc = ctypes.CDLL(None)
+    bad = []
+    for k in range(60):
+        L, E = int(rng.integers(150, 420)), int(rng.integers(5, 13))
+        draft, events, truth = synth.make_region(L, E, 9000 + k, B.oracle_swalign, P0)
+        out = []
+        for api in (hip, orc):
+            libc.srand(100 + k)          # the oracle draws from libc rand(), the HIP library from its per-thread generator
+            hip.srand(100 + k)
+            h = api.align_create(draft, copy.deepcopy(events), P0)
+            try:
+                api.score_alignments(h, E)   # a realign first, as every Mutate call has had (refs from a real backtrace)
+                out.append(api.viterbi_mutate(h, 16, 0.05, 0.01, 0.33, 0.75, 0))
+            finally:
+                api.align_destroy(h)
+        assert len(out[0]) == len(out[1]) == 16
+        bad += [(k, q) for q in range(16) if out[0][q] != out[1][q]]
+    assert not bad, "stochastic Viterbi seeds differ from the oracle: %s" % bad[:10]
+
+
 def test_sw_parity_and_properties():
     rng = np.random.default_rng(5)
     for n1, n2 in [(1, 1), (5, 300), (300, 5), (64, 256), (65, 257), (700, 900), (2100, 1900)]:
@@ -194,11 +221,32 @@ def test_edge_cases_match_oracle():
     assert np.array_equal(scores(mk2(PSAlign).ScorePoints()), scores(mk2(B.OraclePSAlign).ScorePoints()))
     assert B.make_pa(PSAlign, "ACGTACGTAC", [], P0).ScoreEvents() == []
     assert len(B.make_pa(PSAlign, "ACGTACGTAC", [], P0).ScorePoints()) == 48
-    with pytest.raises(_capi.PoreseqError):
-        B.make_pa(PSAlign, draft, copy.deepcopy(events), dict(P0, realign_width=600.0)).ScoreEvents()
+    # a band footprint wider than one workgroup (here: realign_width 2500 covers all ~2850 levels of a 3 kb event) fails loudly
+    d3, e3, _ = synth.make_region(3000, 2, 71, swalign, P0)
+    with pytest.raises(_capi.PoreseqError, match="wider than one workgroup"):
+        B.make_pa(PSAlign, d3, copy.deepcopy(e3), dict(P0, realign_width=2500.0)).ScoreEvents()
     m = MutationInfo(); m.start = -2; m.mut = "A"
     with pytest.raises(_capi.PoreseqError):
         B.make_pa(PSAlign, draft, copy.deepcopy(events), P0).ScoreMutations([m])
+
+
+def test_wide_band_and_many_events_match_oracle():
+    """realign_width 600 (footprint ~620 rows: a 640-lane sweep) and 80 events through ViterbiMutate (the deep-stack build
+    of k_vit_obs), both against the oracle"""
+    Pw = dict(P0, realign_width=600.0)
+    draft, events, truth = synth.make_region(1500, 3, 81, B.oracle_swalign, Pw)
+    mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(events), Pw)
+    assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents()
+    rng = np.random.default_rng(3)
+    muts = synth.random_point_mutations(rng, draft, 60)
+    assert np.array_equal(scores(mk(PSAlign).ScoreMutations(muts)), scores(mk(B.OraclePSAlign).ScoreMutations(muts)))
+    draft, events, truth = synth.make_region(180, 80, 82, B.oracle_swalign, P0)
+    res = []
+    for cls in (PSAlign, B.OraclePSAlign):
+        B.reset_rand()
+        pa = B.make_pa(cls, draft, copy.deepcopy(events), P0)
+        res.append((pa.Mutate(seqs="viterbi", reps=1), pa.sequence))
+    assert res[0] == res[1]
 
 
 def test_realign_to_and_copy():
