@@ -15,49 +15,53 @@ import numpy as np
 from . import poreseqcpp
 
 
+def _report(verbose, text):
+    if verbose > 0:
+        sys.stderr.write(text + "\n")
+
+
 def consensus_region(pa, params=None, reps=4, verbose=0, refseq=None, log=None):
     """Run the consensus schedule in place on `pa`; returns (sequence, accuracy_vs_refseq).
 
-    Mirrors Mutate.py:39-101: fewer than 5 events -> return the input untouched (Mutate.py:50-53);
-    Mutate('self', reps); up to `reps` x {Mutate('viterbi') (inner reps 4), Refine()} stopping when
-    Refine changes nothing; end_trim; accuracy by swalign against the loaded reference.
-    `log`, when given, receives (call, nbases, sequence) after every PSAlign call.
+    The call sequence is the reference's (Mutate.py:39-101) and has to be: a region with fewer than 5 events is handed
+    back untouched (Mutate.py:50-53); otherwise Mutate('self', reps), then up to `reps` rounds of Mutate('viterbi')
+    followed by Refine(), ending after the first Refine that changes nothing; `end_trim` bases come off both ends;
+    the accuracy is the swalign identity against the sequence the region was loaded with.
+    `log`, when given, receives (call, nbases, sequence) after every PSAlign call; `verbose` > 0 prints progress.
     """
     params = pa.params if params is None else params
-    if 'verbose' not in pa.params:
-        pa.params['verbose'] = 0
-    sw = lambda a, b: poreseqcpp.swalign(a, b, pa._native)
+    pa.params.setdefault('verbose', 0)
+    identity = lambda a, b: poreseqcpp.swalign(a, b, pa._native)
     refseq = pa.sequence if refseq is None else refseq
     if len(pa.events) < 5:
-        if verbose > 0:
-            sys.stderr.write("Coverage is 1 or 2, not mutating...\n")
+        _report(verbose, "fewer than 5 events: region returned as loaded")
         return (refseq, 100)
+    _report(verbose, "refining %d bases with %d events" % (len(refseq), len(pa.events)))
+
+    def call(name, fn):
+        n = fn()
+        if log is not None:
+            log.append((name, n, pa.sequence))
+        return n
+
+    call("Mutate:self", lambda: pa.Mutate(reps=reps))
     if verbose > 0:
-        sys.stderr.write("Mutating {} bases using {} events\n".format(len(refseq), len(pa.events)))
-    nb = pa.Mutate(reps=reps)
-    if log is not None:
-        log.append(("Mutate:self", nb, pa.sequence))
-    if verbose > 0:
-        sys.stderr.write("Accuracy: " + str(round(sw(pa.sequence, refseq)[0], 1)) + "%\n")
+        _report(verbose, "identity after seeding from the reads: %.1f%%" % identity(pa.sequence, refseq)[0])
     for _ in range(reps):
-        nb = pa.Mutate(seqs='viterbi')
-        if log is not None:
-            log.append(("Mutate:viterbi", nb, pa.sequence))
-        nbases = pa.Refine()
-        if log is not None:
-            log.append(("Refine", nbases, pa.sequence))
+        call("Mutate:viterbi", lambda: pa.Mutate(seqs='viterbi'))
+        changed = call("Refine", pa.Refine)
         if verbose > 0:
-            sys.stderr.write("Accuracy: " + str(round(sw(pa.sequence, refseq)[0], 1)) + "%\n")
-        if nbases == 0:
+            _report(verbose, "identity: %.1f%%" % identity(pa.sequence, refseq)[0])
+        if changed == 0:
             break
+    trim = int(params['end_trim']) if 'end_trim' in params else 0
     if 'end_trim' in params and len(pa.sequence) > 2 * params['end_trim']:
-        pa.sequence = pa.sequence[int(params['end_trim']):-int(params['end_trim'])]
-    acc, inds = sw(pa.sequence, refseq)
+        pa.sequence = pa.sequence[trim:-trim]
+    acc, pairs = identity(pa.sequence, refseq)
     if verbose > 0:
-        errs = np.sum(np.array(inds) == 0, 0)
-        sys.stderr.write("Final accuracy: " + str(round(acc, 1)) + "%\n")
-        sys.stderr.write("Insertions: {}, Deletions: {}\n".format(errs[0], errs[1]))
-        sys.stderr.write("Final coverage: " + str(round(np.mean(pa.Coverage()), 1)) + "X\n")
+        gaps = np.sum(np.array(pairs) == 0, 0)
+        _report(verbose, "final identity %.1f%%, %d insertions, %d deletions, coverage %.1fX"
+                % (acc, gaps[0], gaps[1], np.mean(pa.Coverage())))
     return (pa.sequence, acc)
 
 
@@ -123,33 +127,42 @@ def variant_region(pa, muts, region_start=0, params=None, out=None):
     return mutscores
 
 
-def train(make_pa, params, refseq, iters=1, reps=10, save=None, paramlists=None, in_flight=1):
-    """Transition-parameter search of `poreseq train` (cmdline.py:246-267): each iteration runs the consensus
-    schedule (reps = 10) once per perturbed parameter set and keeps the most accurate one.
+def train(make_pa, params, refseq, iters=1, reps=10, save=None, paramlists=None, in_flight=1, lock_step=False):
+    """Transition-parameter search of `poreseq train` (cmdline.py:246-267): every iteration runs the consensus schedule
+    (reps = 10) once per candidate parameter set (VaryParams: 16 of them) on the same region and keeps the most accurate.
 
-    make_pa(params) must return a freshly loaded PSAlign for the training region with the event models'
-    transition probabilities taken from `params` (what LoadAlignedEvents + setparams do in the reference);
-    the 16 replicas are independent region work-items.  `paramlists` (optional) replaces VaryParams, e.g.
-    for reproducible tests.  Returns (best params, best accuracy per iteration).
+    make_pa(params) returns a freshly loaded PSAlign of the training region whose event models carry the transition
+    probabilities of `params` (LoadAlignedEvents + setparams in the reference).  `paramlists` (optional, one list per
+    iteration) replaces VaryParams, e.g. for reproducible tests.  Returns (best params, best accuracy per iteration).
 
-    in_flight > 1 runs that many replicas concurrently on the GPU (one host thread each).  The reference runs them
-    one after another in one process, so the stochastic Viterbi seeds of replica k continue the rand() stream
-    of replica k-1; concurrent replicas each continue their own thread's stream instead (as 16 separate
-    `poreseq consensus` processes would), which can change which replica wins by chance — keep 1 for parity.
+    The candidates are independent replicas of one region:
+      lock_step=True   all of them go through the schedule as ONE lock-step batch (poreseq_amd.batch): a single launch
+                       chain per phase, the GPU-native mode.  Each replica draws its stochastic Viterbi seeds from the
+                       generator of a fresh process, i.e. the result is that of 16 separate `poreseq consensus` runs.
+      in_flight=k      k replicas at a time on host threads (same random-stream semantics as lock_step).
+      default          one after another in this thread: replica k continues the rand() stream where replica k-1
+                       stopped, which is what the reference's single process does — bit-parity mode.
+    Which candidate wins can differ between the first two and the last by the luck of the seeds; keep the default
+    when comparing against the reference.
     """
     from .util import VaryParams, SaveParams
     best_accs = []
     for it in range(iters):
-        paramlist = paramlists[it] if paramlists is not None else VaryParams(params)
+        cands = paramlists[it] if paramlists is not None else VaryParams(params)
+
         def one(p):
             return consensus_region(make_pa(p), p, reps=reps, refseq=refseq)[1]
-        if in_flight > 1:
+
+        if lock_step:
+            pas = [make_pa(p) for p in cands]
+            accs = [acc for _, acc in consensus_regions(pas, None, reps=reps, refseqs=[refseq] * len(pas))]
+        elif in_flight > 1:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=int(in_flight)) as pool:
-                accs = list(pool.map(one, paramlist))
+                accs = list(pool.map(one, cands))
         else:
-            accs = [one(p) for p in paramlist]
-        params = paramlist[int(np.argmax(accs))]
+            accs = [one(p) for p in cands]
+        params = cands[int(np.argmax(accs))]
         if save:
             SaveParams(save, params)
         best_accs.append(max(accs))
@@ -171,19 +184,42 @@ def split_regions(length, region_length=10000):
 
 
 def merge_seqs(seq1, seq2, overlap=1000, swalign=None):
-    """Join two region consensus sequences that share `overlap` bases, at the middle of their
-    Smith-Waterman alignment (merge_fasta.py:8-39, same thresholds and index arithmetic)."""
+    """Stitch two region sequences whose ends share about `overlap` bases: the tail of `seq1` is aligned with the head
+    of `seq2` and the join is made at the middle aligned pair.
+
+    Index arithmetic as merge_fasta.py:8-39, quirks included, so that stitched assemblies are identical: a `seq2` shorter
+    than the overlap contributes all but its last base to the alignment; the identity threshold compares a percentage
+    with 0.70; the cut into `seq1` is counted from its END (a middle pair on the tail's last base therefore cuts at 0,
+    i.e. drops `seq1` — the reference's behaviour for degenerate overlaps).
+    """
     swalign = poreseqcpp.swalign if swalign is None else swalign
-    i0, i1 = -overlap, overlap
-    if len(seq1) < overlap:
-        i0 = 0
-    if len(seq2) < overlap:
-        i1 = len(seq2) - 1
-    acc, inds = swalign(seq1[i0:], seq2[:i1])
-    if acc < 0.70:  # sic: a percentage compared with 0.70 (merge_fasta.py:32)
+    tail_from = -overlap if len(seq1) >= overlap else 0
+    head_to = overlap if len(seq2) >= overlap else len(seq2) - 1
+    acc, pairs = swalign(seq1[tail_from:], seq2[:head_to])
+    if acc < 0.70:
         raise Exception('Insufficient accuracy for overlap')
-    inds = [x for x in inds if x[0] > 0 and x[1] > 0]
-    imid = inds[int(len(inds) / 2)]
-    i0 += imid[0]
-    i1 = imid[1]
-    return seq1[:i0] + seq2[i1:]
+    both = [(a, b) for a, b in pairs if a > 0 and b > 0]
+    a_mid, b_mid = both[int(len(both) / 2)]
+    return seq1[:tail_from + a_mid] + seq2[b_mid:]
+
+
+def polish(sequence, make_region_pa, params=None, region_length=10000, overlap=1000, batch=16, reps=4, refine=None):
+    """Assembly polish = the reference's split -> consensus per region -> merge pipeline (split_fasta.py:50-133,
+    `poreseq consensus` per region file, merge_fasta.py:41-80) as one call.
+
+    sequence         the draft to polish (only its length and the region coordinates are used here)
+    make_region_pa   callable (start, end) -> PSAlign loaded with the draft slice and the events overlapping it
+                     (what LoadAlignedEvents returns for region 'start:end')
+    batch            regions refined in lock-step per GPU (poreseq_amd.batch); `refine` replaces the default
+                     `poreseq_amd.dist.refine_regions` (regions sharded over the ranks of the process group, longest first)
+    Returns (polished sequence, [(start, end, region consensus, accuracy)]).  With an `end_trim` in `params` the region
+    sequences lose that many bases per end before stitching, exactly as the region FASTA files of the reference do.
+    """
+    from . import dist as psdist
+    regs = split_regions(len(sequence), region_length)
+    refine = psdist.refine_regions if refine is None else refine
+    done = refine(regs, make_region_pa, params=params, batch=batch, reps=reps)
+    merged = done[0][0]
+    for seq, _ in done[1:]:
+        merged = merge_seqs(merged, seq, overlap)
+    return merged, [(a, b, s, acc) for (a, b), (s, acc) in zip(regs, done)]

@@ -127,7 +127,8 @@ int live_runtimes() { return g_rt_live.load(); }
 RtHolder::~RtHolder() { if (s) { std::lock_guard<std::mutex> lk(g_rt_mu); g_rt_free.push_back(s); g_rt_live--; } }
 
 int second_stream(Runtime* rt, hipStream_t* out) {
-    if (getenv("PORESEQ_ONE_STREAM")) { *out = rt->stream; return PS_OK; }
+    static const bool one = getenv("PORESEQ_ONE_STREAM") != nullptr;   // read once: getenv races with setenv from other threads
+    if (one) { *out = rt->stream; return PS_OK; }
     if (!rt->stream2) PS_HIP(hipStreamCreateWithFlags(&rt->stream2, hipStreamNonBlocking));
     *out = rt->stream2;
     return PS_OK;

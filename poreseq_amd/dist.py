@@ -35,9 +35,21 @@ def device():
     return torch.device("cpu")
 
 
-def shard(items, rank, world):
-    """Round-robin assignment of region work-items to ranks."""
-    return [(i, it) for i, it in enumerate(items) if i % world == rank]
+def shard(items, rank, world, weights=None):
+    """(index, item) pairs of this rank.  Without weights: round-robin.  With weights (e.g. region lengths): longest
+    first onto the least loaded rank (ties: lowest rank) — every rank computes the same assignment, no communication;
+    a ragged tail (the last, short region of a chromosome; config #5's 512 regions over 8 GPUs) then costs at most one
+    region's worth of imbalance instead of a whole round."""
+    if weights is None:
+        return [(i, it) for i, it in enumerate(items) if i % world == rank]
+    load = [0.0] * world
+    mine = []
+    for i in sorted(range(len(items)), key=lambda k: (-float(weights[k]), k)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += float(weights[i])
+        if r == rank:
+            mine.append((i, items[i]))
+    return sorted(mine)
 
 
 def barrier():
@@ -105,10 +117,10 @@ def _fresh_region_rand():
 def run_regions(regions, process, max_events=64, in_flight=1, fresh_rand=_fresh_region_rand):
     """Shard `regions` over the ranks, run process(region) -> (sequence, scores) locally, gather.
 
-    in_flight > 1 refines that many of this rank's regions concurrently on its GPU, one host thread each (the
-    library gives every thread its own streams and device pools; a single region keeps only a few percent of an
-    MI355X busy).  Results do not depend on in_flight: `fresh_rand` (default: ps_srand(1) on the HIP library) is
-    called in the worker before each region.
+    `process` is any per-region callable; in_flight > 1 runs that many of this rank's regions concurrently, one host
+    thread each (the library gives every thread its own stream and device pools).  Results do not depend on in_flight:
+    `fresh_rand` (default: ps_srand(1) on the HIP library) is called in the worker before each region.  For the
+    consensus schedule itself prefer `refine_regions`: lock-step batches keep the GPU full from one thread.
     """
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -121,8 +133,6 @@ def run_regions(regions, process, max_events=64, in_flight=1, fresh_rand=_fresh_
         seq, sc = process(reg)
         return (idx, seq, sc)
 
-    if in_flight > 10:
-        os.environ.setdefault("PORESEQ_ONE_STREAM", "1")   # see second_stream() in csrc/ps_host.cpp
     if in_flight > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=int(in_flight)) as pool:
@@ -130,3 +140,22 @@ def run_regions(regions, process, max_events=64, in_flight=1, fresh_rand=_fresh_
     else:
         local = [one(it) for it in mine]
     return gather_regions(local, len(regions), max_events)
+
+
+def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_events=64):
+    """Consensus for a list of (start, end) regions on all ranks: regions are dealt longest-first to the ranks
+    (`shard` with weights), each rank refines its share in lock-step batches of `batch` regions on its GPU
+    (poreseq_amd.batch), and every rank receives every region's result.  Returns [(sequence, accuracy)] in region order."""
+    from .consensus import consensus_regions
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = shard(regions, rank, world, weights=[b - a for a, b in regions])
+    local = []
+    for k in range(0, len(mine), max(1, int(batch))):
+        chunk = mine[k:k + max(1, int(batch))]
+        pas = [make_region_pa(a, b) for _, (a, b) in chunk]
+        res = consensus_regions(pas, params, reps=reps)
+        for (idx, _), (seq, acc) in zip(chunk, res):
+            local.append((idx, seq, np.array([acc])))
+    got = gather_regions(local, len(regions), max_events)
+    return [(s, float(c[0])) for s, c in got]

@@ -89,18 +89,20 @@ def LoadParams(filename):
     return params
 
 
-def VaryParams(params):
-    '''16 perturbed copies of `params` for one training iteration: three random *_t / *_c keys each scaled by
-    N(1, 0.15) (poreseq/Params.py:31-60; Python's `random`, unseeded, as the reference).'''
+def VaryParams(params, n=16, picks=3, spread=0.15):
+    """One training iteration's candidate parameter sets (poreseq/Params.py:31-60): `n` copies of `params`, each with
+    `picks` distinct transition parameters (keys ending in _t / _c, in dict order) multiplied by a Gaussian factor
+    N(1, spread).  Draws come from Python's global `random`, one `sample` then `picks` `gauss` calls per copy — the
+    reference's order, so a seeded generator gives the reference's list."""
     import random
-    pnames = [x for x in params.keys() if x[-2:] == '_t' or x[-2:] == '_c']
-    paramlist = []
-    for _ in range(16):
-        newparams = params.copy()
-        for k in random.sample(pnames, 3):
-            newparams[k] *= random.gauss(1.0, 0.15)
-        paramlist.append(newparams)
-    return paramlist
+    tunable = [k for k in params.keys() if k.endswith('_t') or k.endswith('_c')]
+    out = []
+    for _ in range(n):
+        cand = params.copy()
+        for k in random.sample(tunable, picks):
+            cand[k] *= random.gauss(1.0, spread)
+        out.append(cand)
+    return out
 
 
 def SaveParams(filename, params):
