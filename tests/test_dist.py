@@ -75,6 +75,41 @@ def test_region_sharding_world2_equals_world1():
     assert all(len(s) > 150 for s in one["seqs"])
 
 
+WORKER_REFINE = r'''
+import copy, os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import backends as B
+from poreseq_amd import dist as psdist, synth
+from poreseq_amd.util import DEFAULT_PARAMS
+rank, local, world = psdist.init(backend="gloo")
+P = dict(DEFAULT_PARAMS, verbose=0)
+P.pop("end_trim")
+regions = [(0, 260), (260, 330), (330, 600), (600, 690), (690, 900)]      # deliberately uneven lengths
+def make(a, b):
+    draft, events, truth = synth.make_region(b - a, 5, 800 + a, B.oracle_swalign, P)
+    return B.make_pa(B.OraclePSAlign, draft, events, P)
+mine = psdist.shard(regions, rank, world, weights=[b - a for a, b in regions])
+res = psdist.refine_regions(regions, make, params=None, batch=2, reps=1)
+loads = psdist.max_over_ranks(sum(b - a for _, (a, b) in mine))
+if rank == 0:
+    print(json.dumps({"world": world, "seqs": [r[0] for r in res], "accs": [r[1] for r in res], "maxload": loads}))
+'''
+
+
+def test_refine_regions_uneven_world2_equals_world1():
+    """lock-step refinement + longest-first sharding: same sequences whatever the world size; the heavier rank carries at
+    most one region more than an even split"""
+    global WORKER
+    keep, WORKER = WORKER, WORKER_REFINE
+    try:
+        one, two = run_world(1), run_world(2)
+    finally:
+        WORKER = keep
+    assert one["seqs"] == two["seqs"] and one["accs"] == two["accs"] and two["world"] == 2
+    assert one["maxload"] == 900 and two["maxload"] <= 450 + 270
+
+
 def test_split_and_merge_regions():
     assert consensus.split_regions(35000, 10000) == [(0, 10000), (9000, 19000), (18000, 28000), (27000, 35000)]
     assert consensus.split_regions(8000, 10000) == [(0, 8000)]

@@ -16,13 +16,21 @@ def test_bench_under_torchrun_single_rank():
     env = dict(os.environ, PORESEQ_FORCE_PG="1")
     out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                                    "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(B.ROOT, "bench.py"),
-                                   "--gpus", "1", "--steps", "1", "--warmup", "0", "--length", "1000", "--no-cpu"],
+                                   "--gpus", "1", "--steps", "1", "--warmup", "0", "--length", "1000", "--regions-per-gpu", "6",
+                                   "--batches-in-flight", "2", "--no-cpu"],
                                   env=env, timeout=900, stderr=subprocess.STDOUT)
     line = [l for l in out.decode().splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["unit"] == "kb/s" and r["scaling"] == "weak"
-    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0 and r["roofline"]["kernel"] == "k_fill"
+    assert r["north_star_1kb"]["lock_step_kb_s"] > r["north_star_1kb"]["single_region_kb_s"] > 0
+    assert r["config"]["batches_in_flight"] == 2 and r["single_region_s"] > 0
     assert r["accuracy"]["consensus_percent"] > 97.0
+
+
+def test_bench_refuses_gpus_without_matching_world():
+    p = subprocess.run([sys.executable, os.path.join(B.ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, timeout=300)
+    assert p.returncode == 2 and b"WORLD_SIZE" in p.stderr
 
 
 def test_rccl_gather_of_region_results():

@@ -65,9 +65,9 @@ def test_consensus_driver_matches_oracle_with_end_trim():
 def test_unsupported_and_limits_fail_loudly():
     draft, events, truth = synth.make_region(200, 3, 74, B.oracle_swalign, P0, draft_error=0.0)
     api = _capi.load_hip()
-    big = [copy.deepcopy(events[k % 3]) for k in range(65)]      # ViterbiMutate handles at most 64 events
+    big = [copy.deepcopy(events[k % 3]) for k in range(257)]     # ViterbiMutate sorts at most 256 events per position
     h = api.align_create(draft, big, P0)
-    with pytest.raises(_capi.PoreseqError):
+    with pytest.raises(_capi.PoreseqError, match="256 events"):
         api.viterbi_mutate(h, 16, 0.05, 0.01, 0.33, 0.75, 0)
     api.align_destroy(h)
     # realign_width 0 makes every alignment a no-op, exactly like the reference's stripe_width == 0
