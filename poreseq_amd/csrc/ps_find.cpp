@@ -14,14 +14,15 @@
 
 namespace ps {
 
-// cap on the DP-matrix bytes of one batch of candidate-sequence alignments: PORESEQ_MAX_BATCH_GB when set (read at
-// every call), otherwise half of the device memory that is free right now divided by the number of host threads that
-// currently own a runtime (each keeps its own grow-only pools)
+// cap on the DP-matrix bytes of one batch of candidate-sequence alignments: PORESEQ_MAX_BATCH_GB when set (read at every
+// call), otherwise a fixed share of the device: 65 % of its memory divided by the number of host threads that currently own
+// a runtime (each keeps its own grow-only pools).  288 GB / 3 lock-step batches -> 62 GB each, i.e. ~230 workgroups of two
+// 10 kb sweeps per launch: about one round of the chip.
 static double max_batch_bytes() {
     if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
     size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess || !fr) return 48e9;
-    return std::max(2e9, 0.5 * (double)fr / std::max(1, live_runtimes()));
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 48e9;
+    return std::max(2e9, 0.65 * (double)tot / std::max(1, live_runtimes()));
 }
 
 static void fillinds(SwResult& al) {  // cpp/swlib.cpp:342-365
@@ -195,7 +196,8 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
             size_t nref = 0;
             while (q1 < need.size()) {
                 const Align* a = as[need[q1].r];
-                const int P = std::max(64, ((a->par.realign_width + 10 + 63) / 64) * 64);
+                // slots per anti-diagonal as realign will size them: footprint ~ (2W + 1) / 1.9 for about one level per base, + 9
+                const int P = std::min(1024, std::max(64, (((2 * a->par.realign_width + 1) * 10 / 19 + 9 + 63) / 64) * 64));
                 double add = 0;
                 for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + need[q1].states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0;
                 if (q1 > q0 && bytes + add > cap) break;

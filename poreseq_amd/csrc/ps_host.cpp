@@ -39,7 +39,7 @@ int DBuf::ensure(size_t bytes) {
     static const bool trace = getenv("PORESEQ_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[ps] pool grow %zu -> %zu bytes\n", cap, bytes);
     if (p) { PS_HIP(hipFree(p)); p = nullptr; cap = 0; }
-    size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+    size_t want = std::max<size_t>(bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30), 1 << 16);   // growth slack, at most 1 GB
     if (hipMalloc(&p, want) != hipSuccess) {
         p = nullptr;
         want = std::max<size_t>(bytes, 1 << 16);
