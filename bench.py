@@ -95,8 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--events", type=int, default=10)
-    ap.add_argument("--regions-per-gpu", type=int, default=48, help="independent regions refined on one GPU per step")
-    ap.add_argument("--batches-in-flight", type=int, default=3,
+    ap.add_argument("--regions-per-gpu", type=int, default=64, help="independent regions refined on one GPU per step")
+    ap.add_argument("--batches-in-flight", type=int, default=4,
                     help="lock-step batches per GPU (one host thread each): while one batch is in a thin phase or on the host, "
                          "the others keep the GPU full; the regions of a step are dealt round-robin to the batches")
     ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")
@@ -189,7 +189,11 @@ def main():
     # synthetic inputs for every step of this rank, generated outside the timed region
     R = max(1, args.regions_per_gpu)
     nsteps = args.warmup + args.steps
-    regions = [[make(1002 + 100000 * rank + 1000 * k + s) for k in range(R)] for s in range(nsteps)]
+    # (at most three distinct sets: generating 25 x 64 regions would take longer than refining them; later steps go round the sets —
+    #  every step recomputes everything, nothing is cached between steps)
+    nsets = min(nsteps, 3)
+    sets = [[make(1002 + 100000 * rank + 1000 * k + s) for k in range(R)] for s in range(nsets)]
+    regions = [sets[s % nsets] for s in range(nsteps)]
 
     pre = {}
     if rank == 0 and not args.no_extras:

@@ -14,16 +14,8 @@
 
 namespace ps {
 
-// cap on the DP-matrix bytes of one batch of candidate-sequence alignments: PORESEQ_MAX_BATCH_GB when set (read at every
-// call), otherwise a fixed share of the device: 65 % of its memory divided by the number of host threads that currently own
-// a runtime (each keeps its own grow-only pools).  288 GB / 3 lock-step batches -> 62 GB each, i.e. ~230 workgroups of two
-// 10 kb sweeps per launch: about one round of the chip.
-static double max_batch_bytes() {
-    if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
-    size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 48e9;
-    return std::max(2e9, 0.65 * (double)tot / std::max(1, live_runtimes()));
-}
+// cap on the DP-matrix bytes of one batch of candidate-sequence alignments: this runtime's share of the device (ps_host.cpp)
+static double max_batch_bytes() { return device_share_bytes(); }
 
 static void fillinds(SwResult& al) {  // cpp/swlib.cpp:342-365
     if (al.a.empty()) return;

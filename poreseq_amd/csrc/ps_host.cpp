@@ -127,8 +127,12 @@ int live_runtimes() { return g_rt_live.load(); }
 RtHolder::~RtHolder() { if (s) { std::lock_guard<std::mutex> lk(g_rt_mu); g_rt_free.push_back(s); g_rt_live--; } }
 
 int second_stream(Runtime* rt, hipStream_t* out) {
-    static const bool one = getenv("PORESEQ_ONE_STREAM") != nullptr;   // read once: getenv races with setenv from other threads
-    if (one) { *out = rt->stream; return PS_OK; }
+    // One stream per runtime as soon as several host threads drive the GPU (lock-step batches in flight): HIP maps streams onto
+    // 4 hardware queues by default, and the 5th stream serialises behind another one — measured: 4 batches x 1 stream 101 kb/s,
+    // 4 batches x 2 streams 69 kb/s; the overlap a second stream buys comes from the other batches anyway.
+    // (PORESEQ_ONE_STREAM forces it for a lone thread too; read once: getenv races with setenv from other threads.)
+    static const bool one = getenv("PORESEQ_ONE_STREAM") != nullptr;
+    if (one || live_runtimes() > 1) { *out = rt->stream; return PS_OK; }
     if (!rt->stream2) PS_HIP(hipStreamCreateWithFlags(&rt->stream2, hipStreamNonBlocking));
     *out = rt->stream2;
     return PS_OK;
@@ -294,6 +298,18 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
     d.maxw = rt->buf("maxw").as<int>();
     d.log2pi = std::log(2 * M_PI);  // cpp/AlignUtil.h:24
     return PS_OK;
+}
+
+// this runtime's share of the device memory for DP matrices (rec + flg = 18 bytes per slot): PORESEQ_MAX_BATCH_GB when set (read
+// at every call), otherwise 65 % of the device divided by four — the pools of a runtime only grow, so the share must not depend on
+// how many host threads happen to drive the GPU at the moment (by more than four, if that many own a runtime).  288 GB -> 47 GB per
+// runtime: a lone region's 170 candidate alignments (24 GB) stay one launch; a lock-step batch of 16 regions takes ~170 workgroups
+// of two 10 kb sweeps per launch.
+double device_share_bytes() {
+    if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 48e9;
+    return std::max(2e9, 0.65 * (double)tot / std::max(4, live_runtimes()));
 }
 
 // second phase: the anti-diagonal footprint of every band is known, size the skewed matrices

@@ -92,6 +92,7 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
 int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<RandState*>& rngs, int nkeep, double skip, double stay,
                          double mmin, double mmax, const std::vector<std::vector<std::string>*>& outs);
 int live_runtimes();   // host threads that currently own a runtime
+double device_share_bytes();   // this runtime's share of the device memory for DP matrices
 int make_mutations_multi(Runtime* rt, const std::vector<Align*>& as, std::vector<std::vector<Mut>> muts, std::vector<int>* nbases);
 int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
                           const std::vector<std::vector<Mut>*>& outs);
