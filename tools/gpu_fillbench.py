@@ -11,7 +11,7 @@ api = _capi.load_hip()
 draft, events, truth = synth.make_region(L, 10, 1002, swalign, P)
 h = api.align_create(draft, copy.deepcopy(events), P)
 api.score_alignments(h, 10)
-if os.environ.get("PS_MODE") == "score":     # realign with both directions (ScoreMutations on a short list)
+if os.environ.get("PS_MODE") == "score" or (len(sys.argv) > 2 and sys.argv[2] == "score"):     # realign with both directions (ScoreMutations on a short list)
     rng = __import__("numpy").random.default_rng(1)
     muts = synth.random_point_mutations(rng, draft, 50)
     hm = api.muts_create(muts)
