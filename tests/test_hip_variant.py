@@ -9,7 +9,7 @@ import pytest
 import backends as B
 from poreseq_amd import _capi, synth
 from poreseq_amd.consensus import variant_region, consensus_region, split_regions
-from poreseq_amd.poreseqcpp import PSAlign
+from poreseq_amd.poreseqcpp import PSAlign, swalign
 from poreseq_amd.util import DEFAULT_PARAMS, MutationInfo
 
 pytestmark = pytest.mark.gpu
@@ -123,3 +123,39 @@ def test_run_regions_in_flight_is_deterministic_and_matches_fresh_process_oracle
     ref = psdist.run_regions(specs[:2], process(B.OraclePSAlign), max_events=8, in_flight=1, fresh_rand=B.reset_rand)
     assert [r[0] for r in ref] == [r[0] for r in one[:2]]
     assert all(np.array_equal(a[1], b[1]) for a, b in zip(ref, one[:2]))
+
+
+def test_chained_smith_waterman_strips_under_load_match_oracle():
+    """10 kb pairs take three chained 4096-column strips per pair (ps_sw.hip: ticket-ordered workgroups, boundary column handed over
+    through global memory).  Eight host threads run such pairs at once, next to a thread that keeps the chip busy with fills; every
+    alignment must equal the oracle's, bit for bit."""
+    import threading
+    rng = np.random.default_rng(77)
+    pairs = []
+    for k in range(8):
+        a = synth.random_sequence(rng, 9000 + 400 * k)
+        pairs.append((a, synth.corrupt(rng, a, 0.04, 0.04, 0.04)))
+    want = [B.oracle_swalign(a, b) for a, b in pairs[:3]]
+    ref3 = [swalign(a, b) for a, b in pairs[:3]]
+    assert ref3 == want                                              # alone: equals the oracle
+    alone = [swalign(a, b) for a, b in pairs]
+    got = [None] * 8
+    stop = threading.Event()
+    draft, events, truth = synth.make_region(4000, 10, 83, swalign, P0)
+
+    def load():
+        while not stop.is_set():
+            B.make_pa(PSAlign, draft, copy.deepcopy(events), P0).ScoreEvents()
+
+    def work(k):
+        for _ in range(3):
+            got[k] = swalign(*pairs[k])
+
+    bg = threading.Thread(target=load)
+    bg.start()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    stop.set()
+    bg.join()
+    assert got == alone
