@@ -511,8 +511,33 @@ void par_for(int n, const std::function<void(int)>& fn) {
     for (std::thread& x : th) x.join();
 }
 
+// How many of the AlignData as[k0..] fit this runtime's device share when each event takes `ndir` sweeps (at least one)
+static size_t fit_share(const std::vector<Align*>& as, size_t k0, int ndir) {
+    const double cap = device_share_bytes();
+    double bytes = 0;
+    size_t k = k0;
+    for (; k < as.size(); k++) {
+        const Align* a = as[k];
+        const int P = std::min(1024, std::max(64, (((2 * a->par.realign_width + 1) * 10 / 19 + 9 + 63) / 64) * 64));
+        double add = 0;
+        for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + a->states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0 * ndir;
+        if (k > k0 && bytes + add > cap) break;
+        bytes += add;
+    }
+    return k;
+}
+
 // ScoreAlignments, cpp/MakeMutations.cpp:148-195, for several AlignData in one launch chain (independent regions in lock-step)
 int score_alignments_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<double*>& scores, const std::vector<double*>& likes) {
+    if (fit_share(as, 0, 1) < as.size()) {   // more matrices than this runtime's share of the device: sub-batches, one after the other
+        for (size_t k0 = 0; k0 < as.size();) {
+            const size_t k1 = fit_share(as, k0, 1);
+            PS_TRY(score_alignments_multi(rt, std::vector<Align*>(as.begin() + k0, as.begin() + k1), std::vector<double*>(scores.begin() + k0, scores.begin() + k1),
+                                          std::vector<double*>(likes.begin() + k0, likes.begin() + k1)));
+            k0 = k1;
+        }
+        return PS_OK;
+    }
     std::vector<JobSpec> specs;
     for (Align* a : as)
         for (int e = 0; e < a->E; e++) {
@@ -663,6 +688,16 @@ static void plan_tables(const Align* a, const std::vector<Mut>& muts, EditPlan* 
 // events (forward + backward of one event share a workgroup), then the edit scoring of each
 int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
                           const std::vector<std::vector<Mut>*>& outs) {
+    if (fit_share(as, 0, 2) < as.size()) {   // sub-batches that fit this runtime's share of the device
+        for (size_t k0 = 0; k0 < as.size();) {
+            const size_t k1 = fit_share(as, k0, 2);
+            PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin() + k0, as.begin() + k1),
+                                         std::vector<const std::vector<Mut>*>(muts.begin() + k0, muts.begin() + k1),
+                                         std::vector<std::vector<Mut>*>(outs.begin() + k0, outs.begin() + k1)));
+            k0 = k1;
+        }
+        return PS_OK;
+    }
     Tick tk("score_mutations");
     const int R = (int)as.size();
     std::vector<EditPlan> plan(R);
@@ -703,7 +738,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     for (int k = 0; k < R; k++) {
         const EditPlan& p = plan[k];
         ints += (size_t)p.M * 7 + (size_t)p.M * p.ncolmax + p.nr0 + 16;
-        dbls += (size_t)as[k]->E * std::max(p.nr0, 1) + (size_t)as[k]->E * std::max(p.M, 1) + std::max(p.M, 1);
+        dbls += (size_t)as[k]->E * std::max(p.nr0, 1) + (size_t)as[k]->E * std::max(p.M, 1) + std::max(p.M, 1) + (size_t)as[k]->E * (as[k]->states.size() + 8);
     }
     DBuf& mb = rt->buf("mutint");
     PS_TRY(mb.ensure(ints * sizeof(int)));
@@ -729,6 +764,11 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         sa.old = dd; dd += (size_t)as[k]->E * std::max(p.nr0, 1);
         sa.delta = dd; dd += (size_t)as[k]->E * std::max(p.M, 1);
         sa.score = dd; dd += std::max(p.M, 1);
+        // edit positions on more than a quarter of the columns: column-pair maxima of ALL columns in one coalesced pass (k_oldall)
+        sa.oldall_pitch = (int64_t)as[k]->states.size() + 8;
+        sa.maxS = b.maxS;
+        sa.oldall = (size_t)p.nr0 * 4 > as[k]->states.size() && p.nr0 >= 256 ? dd : nullptr;
+        dd += (size_t)as[k]->E * sa.oldall_pitch;
     }
     PS_TRY(rt->up(dp, stage.data(), stage.size() * sizeof(int)));
     tk.lap("upload");

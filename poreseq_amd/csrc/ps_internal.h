@@ -195,6 +195,8 @@ struct ScoreArgs {
     const int* r0;             // [nr0] unique max(start-3,1) values
     int nr0;
     double* old;               // [njobs][nr0]
+    double* oldall;            // NULL, or [njobs][oldall_pitch]: column-pair maxima of every column (k_oldall), when the list touches most columns
+    int64_t oldall_pitch, maxS;
     double* delta;             // [njobs][M]
     double* score;             // [M]
 };

@@ -301,17 +301,21 @@ __device__ __forceinline__ double mdiv(double a, double b, double y) {
 // emission log-density (cpp/AlignUtil.h:34-38, 48-53 + cpp/Alignment.cpp:169-173), operation for operation
 // m = {mu, 1/sg, sg, log sg, sm, 1/sm, lambda, log lambda}; lev = {x, sd, 3 log sd, 1/sd}
 template <bool FASTDIV>
-__device__ __forceinline__ double fill_emission(const FillCtx& c, const double (&m)[8], const double (&lev)[4]) {
+__device__ __forceinline__ double emission8(const double (&m)[8], const double (&lev)[4], const double log2pi, const double off) {
     const double a1 = lev[0] - m[0], a2 = lev[1] - m[4];
     const double d = FASTDIV ? mdiv(a1, m[2], m[1]) : a1 / m[2];
     const double e = FASTDIV ? mdiv(a2, m[4], m[5]) : a2 / m[4];
-    double l = -0.5 * (d * d + c.log2pi) - m[3];
+    double l = -0.5 * (d * d + log2pi) - m[3];
     const double t = e * e * m[6];
     const double q = FASTDIV ? mdiv(t, lev[1], lev[3]) : t / lev[1];
-    const double g = 0.5 * (m[7] - lev[2] - c.log2pi - q);
+    const double g = 0.5 * (m[7] - lev[2] - log2pi - q);
     l += g;
-    l += c.off;
+    l += off;
     return l;
+}
+template <bool FASTDIV>
+__device__ __forceinline__ double fill_emission(const FillCtx& c, const double (&m)[8], const double (&lev)[4]) {
+    return emission8<FASTDIV>(m, lev, c.log2pi, c.off);
 }
 
 __device__ __forceinline__ void fill_model_row(const FillCtx& c, int state, double (&m)[8]) {
@@ -843,10 +847,104 @@ __global__ __launch_bounds__(64) void k_old(BatchD b, ScoreArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// columnMax(j, C - j + 1) for EVERY column j at once (the `old` score of all edit positions of a Refine / ScorePoints list).
+// Cell (i, j) of the forward matrix lies on anti-diagonal s = i + j; its partner (n0 - i + 1, C - j + 1) of the backward matrix lies
+// on anti-diagonal n0 + C + 2 - s, in the mirrored slot order: one pass over the anti-diagonals reads both matrices fully coalesced
+// (32 B per cell), where one wave per column (k_old) touches a 128-byte line per 16-byte record.  Sums of two non-negative scores
+// are maximised per column through an LDS window and one global atomic per touched column; max is order-independent, so the result
+// is the reference's.  grid (ceil(S / OA_SB), njobs), block 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int OA_SB = 32;      // anti-diagonals per block
+constexpr int OA_COLS = 2048;  // column window of a block in LDS
+__global__ __launch_bounds__(256) void k_oldall(BatchD b, ScoreArgs a) {
+    __shared__ unsigned long long s_max[OA_COLS];
+    __shared__ int s_jbase, s_ok;
+    const JobD& J = b.jobs[a.job0 + blockIdx.y];
+    if (J.out->inert) return;
+    const int s0 = blockIdx.x * OA_SB;
+    const int S = (int)J.S, P = J.P, n0 = J.n0, C = J.C;
+    if (s0 >= S) return;
+    const int nst = min(OA_SB, S - s0);
+    const int* __restrict__ LOf = b.lo + J.lo_off[0];
+    const int* __restrict__ HIf = b.hi + J.lo_off[0];
+    const int* __restrict__ LOb = b.lo + J.lo_off[1];
+    const int* __restrict__ HIb = b.hi + J.lo_off[1];
+    if (threadIdx.x == 0) {
+        int jmin = 0x7fffffff, jmax = -1;
+        for (int k = 0; k < nst; k++) {
+            const int lo = LOf[s0 + k];
+            if (lo < 0) continue;
+            jmax = max(jmax, s0 + k - lo);
+            jmin = min(jmin, s0 + k - HIf[s0 + k]);
+        }
+        s_jbase = jmin;
+        s_ok = jmax < 0 ? -1 : (jmax - jmin + 1 <= OA_COLS ? 1 : 0);
+    }
+    for (int k = threadIdx.x; k < OA_COLS; k += 256) s_max[k] = 0ull;
+    __syncthreads();
+    if (s_ok < 0) return;
+    const bool use_lds = s_ok == 1;
+    const int jbase = s_jbase;
+    const double2* __restrict__ rf = b.rec + J.mat_off[0];
+    const double2* __restrict__ rb = b.rec + J.mat_off[1];
+    unsigned long long* gmax = (unsigned long long*)(a.oldall + (size_t)blockIdx.y * a.oldall_pitch);
+    const int nP = P >> 6, lane = threadIdx.x & 63;
+    int k = 0, c = threadIdx.x >> 6;
+    while (c >= nP) { c -= nP; k++; }
+    for (; k < nst;) {
+        const int s = s0 + k;
+        const int slot = c * 64 + lane;
+        const int lo = __builtin_amdgcn_readfirstlane(LOf[s]), hi = __builtin_amdgcn_readfirstlane(HIf[s]);
+        c += 4;
+        while (c >= nP) { c -= nP; k++; }
+        if (lo < 0) continue;
+        int d = slot - lo % P;
+        if (d < 0) d += P;
+        const int i = lo + d;
+        if (i > hi) continue;
+        const int j = s - i;
+        const int jb = n0 - i + 1, cb = C - j + 1, sb = jb + cb;      // partner cell in backward coordinates
+        if (cb < 1) continue;                                           // (column j = C + 1 does not exist; cb = 0 is the blank column: sums with zero, covered by pm)
+        const int lob = LOb[sb];
+        if (lob < 0 || jb < lob || jb > HIb[sb]) continue;              // partner outside the backward band
+        const double2 fv = rf[(int64_t)s * P + slot];
+        const double2 bv = rb[(int64_t)sb * P + jb % P];
+        const double v = fmax(fv.x + bv.x, fv.y + bv.y);
+        if (v > 0.0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            if (use_lds) atomicMax(&s_max[j - jbase], bits); else atomicMax(&gmax[j], bits);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < OA_COLS; q += 256) {
+            const unsigned long long v = s_max[q];
+            if (v) atomicMax(&gmax[jbase + q], v);
+        }
+    }
+}
+
+// old[r0] = max(0, column sums, forward MaxInfo up to r0, backward MaxInfo up to C - r0 + 1)  (cpp/Alignment.h:181-214); grid (ceil(nr0/256), njobs)
+__global__ __launch_bounds__(256) void k_oldfin(BatchD b, ScoreArgs a) {
+    const JobD& J = b.jobs[a.job0 + blockIdx.y];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.nr0 || J.out->inert) return;
+    const int C = J.C;
+    int raf = a.r0[q], rab = C - raf + 1;
+    double sm = 0.0;
+    if ((unsigned)raf >= (unsigned)(C + 1)) raf = C;           // columnMax's own clamping (cpp/Alignment.h:186-189)
+    else sm = (a.oldall + (size_t)blockIdx.y * a.oldall_pitch)[raf];
+    if ((unsigned)rab >= (unsigned)(C + 1)) rab = C;
+    sm = fmax(sm, b.pm[J.col_off[0] + raf]);
+    sm = fmax(sm, b.pm[J.col_off[1] + rab]);
+    a.old[(size_t)blockIdx.y * a.nr0 + q] = sm;
+}
+
+// ------------------------------------------------------------------------------------------------
 // scoreMutation (cpp/Alignment.cpp:447-512): G lanes per (event, edit) item, lane = new column,
 // rows stream through the group systolically (lane c works on row  base + t - c  at step t).
 // ------------------------------------------------------------------------------------------------
-template <int G>
+template <int G, bool FD>
 __global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int* __restrict__ items, int nitems) {
     constexpr int IPW = 64 / G;
     __shared__ double s_carry[(G == 64) ? 4 * 1024 : 1];   // last column of a 64-column chunk, per wave
@@ -871,12 +969,9 @@ __global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int*
     if ((unsigned)backind >= (unsigned)(C + 1)) backind = C;
     const int* __restrict__ lbf = b.lb + J.lb_off;    // tables the fills were made with
     const int* __restrict__ lbn = b.lb + J.lbn_off;   // after the backtrace: centres of the new columns
-    const double* __restrict__ mean = J.mean;
-    const double* __restrict__ stdv = J.stdv;
-    const double* __restrict__ lsdv = J.lsd;
+    const double4* __restrict__ levf = (const double4*)J.lev[0];
     const double2* __restrict__ rf = b.rec + J.mat_off[0];
     const double2* __restrict__ rb = b.rec + J.mat_off[1];
-    const double* gm = J.model;
     const double lsk = J.lsk, lst = J.lst, lex = J.lex, lin = J.lin;
 
     // band of the back column the target is combined with
@@ -904,8 +999,13 @@ __global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int*
             i0 = max(1, ce - WS); i1 = min(n0, ce + WS);
             state = a.m_states[(size_t)m * a.ncolmax + cc];
         }
-        ModelRow mr = {0, 1, 0, 1, 0, 0};
-        if (state >= 0) mr = {gm[state], gm[NS + state], gm[2 * NS + state], gm[3 * NS + state], gm[4 * NS + state], gm[5 * NS + state]};
+        // the column's model row as k_fill uses it: {mean, 1/stdv, stdv, log stdv, sd mean, 1/sd mean, lambda, log lambda}
+        double mr[8] = {0, 1, 1, 0, 1, 1, 0, 0};
+        if (state >= 0) {
+            const double2* row = (const double2*)((const char*)J.model8 + (size_t)state * MODEL_ROW_BYTES);
+            const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+            mr[0] = q0.x; mr[1] = q0.y; mr[2] = q1.x; mr[3] = q1.y; mr[4] = q2.x; mr[5] = q2.y; mr[6] = q3.x; mr[7] = q3.y;
+        }
         // band of the column to the left
         int p0 = __shfl_up(i0, 1), p1 = __shfl_up(i1, 1);
         if (c == 0) { p0 = pc0; p1 = pc1; }
@@ -931,7 +1031,9 @@ __global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int*
             if (mine && i >= i0 && i <= i1) {
                 double nm = 0.0, ns = 0.0;
                 if (state >= 0) {
-                    const double o = emission(mr, mean[i - 1], stdv[i - 1], lsdv[n0 - i], b.log2pi, J.lik_offset);
+                    const double4 lv4 = levf[i - 1];   // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
+                    const double lev[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+                    const double o = emission8<FD>(mr, lev, b.log2pi, J.lik_offset);
                     const bool vl = i >= p0 && i <= p1, vd = i > p0 && i <= p1;
                     const double cSKIP = vl ? L + lsk : lsk;
                     const double cMATCH = vd ? D + o : o;
@@ -1120,7 +1222,13 @@ int launch_begin(Runtime* rt, const BatchD& b) {
 int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* const cls_items[4], const int cls_count[4]) {
     const int njobs = a.njobs;   // the jobs [a.job0, a.job0 + njobs) of the batch belong to the AlignData being scored
     if (!njobs || !a.nitems_per_job) return PS_OK;
-    if (a.nr0 > 0) {
+    if (a.nr0 > 0 && a.oldall) {
+        // a list that touches most columns (Refine, ScorePoints): one coalesced pass over both matrices serves every position
+        PS_HIP(hipMemsetAsync(a.oldall, 0, (size_t)njobs * a.oldall_pitch * sizeof(double), rt->stream));
+        hipLaunchKernelGGL(k_oldall, dim3((unsigned)((a.maxS + OA_SB - 1) / OA_SB), njobs), dim3(256), 0, rt->stream, b, a);
+        hipLaunchKernelGGL(k_oldfin, dim3((a.nr0 + 255) / 256, njobs), dim3(256), 0, rt->stream, b, a);
+        PS_LAUNCH_CHECK();
+    } else if (a.nr0 > 0) {
         hipLaunchKernelGGL(k_old, dim3(a.nr0, njobs), dim3(64), 0, rt->stream, b, a);
         PS_LAUNCH_CHECK();
     }
@@ -1130,10 +1238,10 @@ int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* co
         if (!n) continue;
         const int G = 8 << k, ipb = 4 * (64 / G);
         dim3 grid((n + ipb - 1) / ipb, njobs), block(256);
-        if (k == 0) hipLaunchKernelGGL(k_score<8>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
-        else if (k == 1) hipLaunchKernelGGL(k_score<16>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
-        else if (k == 2) hipLaunchKernelGGL(k_score<32>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
-        else hipLaunchKernelGGL(k_score<64>, grid, block, 0, rt->stream, b, a, cls_items[k], n);
+#define PS_SCORE(GG) do { if (b.fastdiv) hipLaunchKernelGGL((k_score<GG, true>), grid, block, 0, rt->stream, b, a, cls_items[k], n); \
+                          else hipLaunchKernelGGL((k_score<GG, false>), grid, block, 0, rt->stream, b, a, cls_items[k], n); } while (0)
+        if (k == 0) PS_SCORE(8); else if (k == 1) PS_SCORE(16); else if (k == 2) PS_SCORE(32); else PS_SCORE(64);
+#undef PS_SCORE
         PS_LAUNCH_CHECK();
     }
     prof_end(rt, "score", 0.0);
