@@ -230,6 +230,50 @@ def test_edge_cases_match_oracle():
         B.make_pa(PSAlign, draft, copy.deepcopy(events), P0).ScoreMutations([m])
 
 
+def test_tiny_sequences_match_oracle():
+    """sequences of 5 .. 40 bases (1 .. 36 states; fewer states than the four-state prefetch window of k_fill)"""
+    for L, seed in ((5, 1), (6, 2), (8, 3), (12, 4), (40, 5)):
+        draft, events, truth = synth.make_region(max(L, 30), 3, 400 + seed, B.oracle_swalign, P0, draft_error=0.0)
+        short = draft[:L]
+        ev = copy.deepcopy(events)
+        for e in ev:
+            e.ref_align[e.ref_align > L - 4] = 0
+        mk = lambda cls: B.make_pa(cls, short, copy.deepcopy(ev), P0)
+        assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents(), L
+        assert np.array_equal(scores(mk(PSAlign).ScorePoints()), scores(mk(B.OraclePSAlign).ScorePoints())), L
+
+
+def test_bands_that_jump_and_resume_match_oracle():
+    """Narrow bands on events whose ref_align jumps (levels cut out, alignments shifted): the band leaves empty anti-diagonals
+    behind and resumes further down — k_fill's SLOW bodies in the middle of a sweep, rows jumping by more than P — against the oracle,
+    matrices included."""
+    rng = np.random.default_rng(5)
+    for W, seed in ((3, 1), (5, 2), (8, 3), (17, 4)):
+        Pn = dict(P0, realign_width=float(W), scoring_width=4.0, point_width=3.0)
+        draft, events, truth = synth.make_region(420, 4, 300 + seed, B.oracle_swalign, Pn)
+        ev = copy.deepcopy(events)
+        for e in ev:
+            n = e.ref_align.size
+            a, b = sorted(rng.integers(20, n - 20, 2))
+            e.ref_align[a:b] = 0                                   # an unaligned stretch: interpolated ref_index
+            c = int(rng.integers(20, n - 60))
+            e.ref_align[c:c + 40] = np.minimum(e.ref_align[c:c + 40] + 90, len(draft) - 5) * (e.ref_align[c:c + 40] > 0)   # a jump forward
+        mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(ev), Pn)
+        assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents(), W
+        assert np.array_equal(scores(mk(PSAlign).ScorePoints()), scores(mk(B.OraclePSAlign).ScorePoints())), W
+        hip, orc = _capi.load_hip(), B.oracle_api()
+        for d in (0, 1):
+            out = []
+            for api in (hip, orc):
+                h = api.align_create(draft, copy.deepcopy(ev), Pn)
+                out.append(api.debug_fill(h, 1, d, ev[1].mean.size, len(draft) - 4))
+                api.align_destroy(h)
+            for x, y in zip(out[0][:2], out[1][:2]):
+                assert np.array_equal(x, y, equal_nan=True), (W, d)
+            if d == 0:
+                assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3]), W
+
+
 def test_wide_band_and_many_events_match_oracle():
     """realign_width 600 (footprint ~620 rows: a 640-lane sweep) and 80 events through ViterbiMutate (the deep-stack build
     of k_vit_obs), both against the oracle"""
