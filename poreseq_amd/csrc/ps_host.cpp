@@ -245,7 +245,7 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
         // widest possible footprint 2W + 1, plus the idle slots k_fill wants between two rows of a lane; the slots actually
         // used follow the measured footprint (realign), typically (2W + 1) / (1 + levels per base) + 9
         const int pm = std::max(64, ((2 * W + 10 + 63) / 64) * 64);
-        Pmax = std::max(Pmax, std::min(pm, 1024));
+        Pmax = std::max(Pmax, std::min(pm, 2048));
         JobD j;
         memset(&j, 0, sizeof(j));
         j.mean = a->d_mean + a->off[s.ev]; j.stdv = a->d_stdv + a->off[s.ev]; j.lsd = a->d_lsd + a->off[s.ev];
@@ -488,10 +488,11 @@ int realign(Runtime* rt, Batch& b) {
     PS_HIP(hipStreamSynchronize(rt->stream));
     // nine slots more than the widest footprint: a lane idles at least nine anti-diagonals between two rows, so a prefetch
     // window of k_fill (fetched six steps ahead, four steps long) never spans two rows of a lane that has a cell
-    if (std::max(*w, 1) + 9 > 1024)
-        return fail(PS_ERR_UNSUPPORTED, "band footprint of " + std::to_string(*w) + " rows on one anti-diagonal: wider than one workgroup (1015); "
-                                        "realign_width up to ~980 fits for events with about one level per base");
-    PS_TRY(b.place(rt, std::max(*w, 1) + 9));
+    // (a footprint beyond 1015 rows takes k_fill_wide: two slots per thread, up to 2048 slots, P a multiple of 128)
+    if (std::max(*w, 1) + 2 > 2048)
+        return fail(PS_ERR_UNSUPPORTED, "band footprint of " + std::to_string(*w) + " rows on one anti-diagonal: wider than two slots per lane of one "
+                                        "workgroup (2046); realign_width up to 1022 fits for any input");
+    PS_TRY(b.place(rt, std::max(*w, 1) + 9 <= 1024 ? std::max(*w, 1) + 9 : ((std::max(*w, 1) + 2 + 127) / 128) * 128));
     if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs * b.ndir; }
     PS_TRY(launch_fill(rt, b.d, b.jobs, b.ndir, b.maxS, b.P, b.ncols));
     PS_TRY(launch_backtrace(rt, b.d, b.maxn));

@@ -595,6 +595,152 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const 
         gcmax[col] = __longlong_as_double((long long)*(unsigned long long*)(c.ring + (((unsigned)col * 8u) & c.ringmask)));
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_fill_wide: the same sweep for bands whose footprint does not fit one lane per row (more than 1015 rows on an anti-diagonal:
+// realign_width beyond ~500 in the worst case, ~980 for events with one level per base).  Every thread holds TWO slots (t and
+// t + blockDim), so a workgroup of up to 1024 threads carries up to 2048 slots (realign_width <= 1022 for any input).  This is the
+// plain form of k_fill — no prefetch windows, no software pipeline, model rows read from global memory (two 98 KB exchange buffers
+// leave no room for the table in LDS), one sweep per workgroup — i.e. the width is supported, not tuned: ~4x the time per cell.
+// Cell arithmetic, flags, codes and column maxima are the same expressions as in fill_step.
+// ------------------------------------------------------------------------------------------------
+template <int DIR, bool FD>
+__device__ __forceinline__ void fill_wide_body(const BatchD& b, const JobD& J, char* smem, const int rcols) {
+    constexpr int R = 2;
+    const int T = blockDim.x, P = J.P, tid = threadIdx.x, C = J.C, S = (int)J.S;
+    const int* __restrict__ LO = b.lo + J.lo_off[DIR];
+    const int* __restrict__ HI = b.hi + J.lo_off[DIR];
+    double2* __restrict__ rec = b.rec + J.mat_off[DIR];
+    unsigned short* __restrict__ flg = b.flg + J.mat_off[DIR];
+    const double4* __restrict__ levs = (const double4*)J.lev[DIR];
+    const int* __restrict__ st = J.st;
+    const char* __restrict__ model = (const char*)J.model8;
+    const double lsk = J.lsk, lst = J.lst, lex = J.lex, lin = J.lin, off = J.lik_offset, log2pi = b.log2pi;
+    const double NINF = -__builtin_inf();
+    double* xch = (double*)smem;                                  // [2][P][3]
+    unsigned long long* ring = (unsigned long long*)(smem + (size_t)2 * P * 24);
+    const unsigned ringmask = (unsigned)rcols - 1u;
+    for (int k = tid; k < 2 * P * 3; k += T) xch[k] = NINF;
+    for (int k = tid; k < rcols; k += T) ring[k] = 0ull;
+    double cm[R], cs[R], dm[R], de[R];
+    int row[R];
+    bool pin[R], ptop[R], pdead[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int slot = tid + r * T;
+        cm[r] = NINF; cs[r] = NINF; dm[r] = NINF; de[r] = NINF;
+        row[r] = slot == 0 ? P : slot;
+        pin[r] = false; ptop[r] = false; pdead[r] = false;
+    }
+    __syncthreads();
+    double* gcmax = b.cmax + J.col_off[DIR];
+    int lo_p = -1, flushed = 1;
+    for (int s = 2; s < S; s++) {
+        const int lo = LO[s], hi = HI[s];
+        const bool newcol = lo_p < 0 || lo == lo_p;
+        const int par = s & 1;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int slot = tid + r * T;
+            int i = row[r];
+            if (lo >= 0 && i < lo) {
+                i += P;
+                if (i < lo) { int d = (slot - lo) % P; if (d < 0) d += P; i = lo + d; }
+            }
+            row[r] = i;
+            const bool inb = lo >= 0 && i <= hi;
+            const bool top = inb && newcol && i == lo;
+            const int j = s - i;
+            const bool first = j == 1;
+            const double* up = xch + ((size_t)(par ^ 1) * P + (slot == 0 ? P - 1 : slot - 1)) * 3;
+            const double um = up[0], us = up[1], ue = up[2];
+            double o = 0.0;
+            bool dead = false;
+            if (inb) {
+                const int state = st[DIR == 0 ? j - 1 : C - j];
+                dead = state < 0;
+                if (!dead) {
+                    const double2* q = (const double2*)(model + (size_t)state * MODEL_ROW_BYTES);
+                    const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                    const double m[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+                    const double4 l4 = levs[i - 1];
+                    const double lev[4] = {l4.x, l4.y, l4.z, l4.w};
+                    o = emission8<FD>(m, lev, log2pi, off);
+                }
+            }
+            const bool vd = first || (pin[r] && !ptop[r]);
+            const bool rd = !first && pin[r] && !ptop[r] && !pdead[r];
+            double L;
+            asm("v_max_f64 %0, %1, 0" : "=v"(L) : "v"(cm[r]));
+            const double D = rd ? dm[r] : 0.0;
+            const double cSTAY = DIR == 0 ? um + o + lst : ue + lst;
+            const double cEXT = DIR == 0 ? us + o + lex : us + lex;
+            const double cINS = um + lin;
+            const double cSKIP = L + lsk;
+            const double cMATCH = DIR == 0 ? D + o : (rd ? de[r] : 0.0);
+            const double cIGN = D + lin;
+            const double floor_s = top ? -BIG : 0.0;
+            double ns = fmax(floor_s, cSTAY);
+            ns = fmax(ns, cEXT);
+            double nm = fmax(0.0, cSKIP);
+            nm = fmax(nm, cMATCH);
+            nm = fmax(nm, cINS);
+            nm = fmax(nm, cIGN);
+            nm = fmax(nm, ns);
+            const bool act = inb && !dead;
+            cm[r] = act ? nm : NINF;
+            cs[r] = act ? ns : NINF;
+            double rx;
+            asm("v_max_f64 %0, %1, 0" : "=v"(rx) : "v"(cm[r]));
+            const int64_t cell = (int64_t)s * P + slot;
+            rec[cell] = make_double2(rx, act ? ns : 0.0);
+            if (DIR == 0) {
+                unsigned ss = cSTAY > floor_s ? M_STAY : 0u;
+                ss = cEXT > fmax(floor_s, cSTAY) ? M_EXTEND : ss;
+                unsigned sm = M_STAY;
+                sm = cIGN == nm ? M_IGNORE : sm;
+                sm = cINS == nm ? M_INSERT : sm;
+                sm = cMATCH == nm ? (vd ? M_MATCH : M_IMPL) : sm;
+                sm = cSKIP == nm ? M_SKIP : sm;
+                sm = nm > 0.0 ? sm : 0u;
+                const unsigned w = sm | (ss << 8) | (nm > 0.0 ? 0u : 0x4000u) | (ns > 0.0 ? 0u : 0x8000u);
+                flg[cell] = (unsigned short)(act ? w : FLG_DEAD);
+            }
+            double* mine = xch + ((size_t)par * P + slot) * 3;
+            if (DIR == 0) { mine[0] = cm[r]; mine[1] = cs[r]; }
+            else { mine[0] = cm[r]; mine[1] = cs[r] + o; mine[2] = cm[r] + o; }
+            if (act && rx > 0.0) atomicMax(&ring[(unsigned)j & ringmask], (unsigned long long)__double_as_longlong(rx));
+            dm[r] = um; de[r] = ue;
+            pin[r] = inb; ptop[r] = top; pdead[r] = dead;
+        }
+        lo_p = lo;
+        __syncthreads();
+        if ((s & 63) == 63 && s + 1 < S) {   // flush the maxima of completed columns (left of the oldest column still present)
+            const int lo_n = LO[s + 1];
+            if (lo_n >= 0) {
+                const int jdone = s + 1 - HI[s + 1];
+                for (int col = flushed + tid; col < jdone; col += T) {
+                    const unsigned long long v = ring[(unsigned)col & ringmask];
+                    ring[(unsigned)col & ringmask] = 0ull;
+                    gcmax[col] = __longlong_as_double((long long)v);
+                }
+                flushed = max(flushed, jdone);
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int col = flushed + tid; col <= C; col += T) gcmax[col] = __longlong_as_double((long long)ring[(unsigned)col & ringmask]);
+}
+
+template <bool FD>
+__global__ __launch_bounds__(1024) void k_fill_wide(BatchD b, int ndir, int rcols) {
+    extern __shared__ double2 fill_smem[];
+    const int jd = blockIdx.x, job = jd / ndir, dir = jd % ndir;
+    const JobD& J = b.jobs[job];
+    if (J.out->inert) return;
+    if (dir == 0) fill_wide_body<0, FD>(b, J, (char*)fill_smem, rcols); else fill_wide_body<1, FD>(b, J, (char*)fill_smem, rcols);
+}
+
 // the barrier sequence of fill_body for a half without a sweep (no partner, or an inert job)
 __device__ __forceinline__ void fill_idle(const int Smax) {
     __syncthreads();
@@ -1165,6 +1311,24 @@ int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int
         attr_set = true;
     }
     PS_HIP(hipMemsetAsync(b.cmax, 0, ncols * sizeof(double), rt->stream));
+    if (P > 1024) {   // footprint wider than one lane per row: the two-slots-per-thread sweep
+        static bool wide_attr = false;
+        if (!wide_attr) {
+            PS_HIP(hipFuncSetAttribute((const void*)k_fill_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PS_HIP(hipFuncSetAttribute((const void*)k_fill_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            wide_attr = true;
+        }
+        const int rc = 4096;
+        const size_t lds = (size_t)2 * P * 24 + (size_t)rc * 8;
+        prof_begin(rt);
+        if (b.fastdiv) hipLaunchKernelGGL(k_fill_wide<true>, dim3(b.njobs * ndir), dim3(P / 2), lds, rt->stream, b, ndir, rc);
+        else hipLaunchKernelGGL(k_fill_wide<false>, dim3(b.njobs * ndir), dim3(P / 2), lds, rt->stream, b, ndir, rc);
+        PS_LAUNCH_CHECK();
+        prof_end(rt, "fill", 0.0);
+        hipLaunchKernelGGL(k_prefix, dim3(b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
+        PS_LAUNCH_CHECK();
+        return PS_OK;
+    }
     // workgroups: two sweeps over the same event share one (model table in LDS): forward + backward of a job, or two
     // forward-only jobs of one event (candidate sequences of FindMutations), longest with longest
     // (a launch that fits the chip with one sweep per workgroup keeps them apart: a lone sweep finishes ~20 % sooner than a pair,

@@ -221,10 +221,11 @@ def test_edge_cases_match_oracle():
     assert np.array_equal(scores(mk2(PSAlign).ScorePoints()), scores(mk2(B.OraclePSAlign).ScorePoints()))
     assert B.make_pa(PSAlign, "ACGTACGTAC", [], P0).ScoreEvents() == []
     assert len(B.make_pa(PSAlign, "ACGTACGTAC", [], P0).ScorePoints()) == 48
-    # a band footprint wider than one workgroup (here: realign_width 2500 covers all ~2850 levels of a 3 kb event) fails loudly
-    d3, e3, _ = synth.make_region(3000, 2, 71, swalign, P0)
-    with pytest.raises(_capi.PoreseqError, match="wider than one workgroup"):
-        B.make_pa(PSAlign, d3, copy.deepcopy(e3), dict(P0, realign_width=2500.0)).ScoreEvents()
+    # a band footprint wider than two slots per lane of one workgroup (here: realign_width 5000 covers all ~4750 levels of a 5 kb
+    # event: ~2400 rows per anti-diagonal) fails loudly
+    d3, e3, _ = synth.make_region(5000, 2, 71, swalign, P0)
+    with pytest.raises(_capi.PoreseqError, match="wider than two slots per lane"):
+        B.make_pa(PSAlign, d3, copy.deepcopy(e3), dict(P0, realign_width=5000.0)).ScoreEvents()
     m = MutationInfo(); m.start = -2; m.mut = "A"
     with pytest.raises(_capi.PoreseqError):
         B.make_pa(PSAlign, draft, copy.deepcopy(events), P0).ScoreMutations([m])
@@ -284,6 +285,23 @@ def test_wide_band_and_many_events_match_oracle():
     rng = np.random.default_rng(3)
     muts = synth.random_point_mutations(rng, draft, 60)
     assert np.array_equal(scores(mk(PSAlign).ScoreMutations(muts)), scores(mk(B.OraclePSAlign).ScoreMutations(muts)))
+    # realign_width 1000 on a 3 kb region: ~1030 rows per anti-diagonal, more than one lane per row -> k_fill_wide (two slots per thread)
+    Pv = dict(P0, realign_width=1000.0)
+    draft, events, truth = synth.make_region(3000, 2, 83, B.oracle_swalign, Pv)
+    mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(events), Pv)
+    assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents()
+    muts = synth.random_point_mutations(rng, draft, 40)
+    assert np.array_equal(scores(mk(PSAlign).ScoreMutations(muts)), scores(mk(B.OraclePSAlign).ScoreMutations(muts)))
+    hip, orc = _capi.load_hip(), B.oracle_api()
+    for d in (0, 1):
+        out = []
+        for api in (hip, orc):
+            h = api.align_create(draft, copy.deepcopy(events), Pv)
+            out.append(api.debug_fill(h, 0, d, events[0].mean.size, len(draft) - 4))
+            api.align_destroy(h)
+        assert np.array_equal(out[0][0], out[1][0], equal_nan=True) and np.array_equal(out[0][1], out[1][1], equal_nan=True), d
+        if d == 0:
+            assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
     draft, events, truth = synth.make_region(180, 80, 82, B.oracle_swalign, P0)
     res = []
     for cls in (PSAlign, B.OraclePSAlign):
