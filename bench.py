@@ -281,6 +281,7 @@ def main():
         if cpu_pre is not None:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import backends as B
+            B.build_oracle = lambda: None     # this process holds the GPU: never start a build from here (the children above did, if needed)
             use_ref = cpu_pre["use_ref"]
             cls = B.RefPSAlign if use_ref else B.OraclePSAlign
             cpu_sw = B.ref_swalign if use_ref else B.oracle_swalign
