@@ -2,7 +2,9 @@
 
 `poreseq_amd.poreseqcpp` mirrors the reference's compiled module (`PSAlign`, `swalign`,
 `seqtostates`); `poreseq_amd.consensus` reproduces the call schedule of the reference's
-consensus / variant drivers on top of it.
+consensus / variant / train drivers on top of it (`consensus_region`, lock-step `consensus_regions`,
+`polish`); `poreseq_amd.batch.RegionBatch` runs the PSAlign calls of several regions in lock-step on one
+GPU; `poreseq_amd.dist` shards regions over one process per GPU.
 """
 from .util import RegionInfo, MutationInfo, MutationScore, LoadParams, SaveParams, VaryParams, DEFAULT_PARAMS  # noqa: F401
 from .events import PSEvent, PSModel  # noqa: F401

@@ -248,8 +248,6 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
         Pmax = std::max(Pmax, std::min(pm, 2048));
         JobD j;
         memset(&j, 0, sizeof(j));
-        j.mean = a->d_mean + a->off[s.ev]; j.stdv = a->d_stdv + a->off[s.ev]; j.lsd = a->d_lsd + a->off[s.ev];
-        j.model = a->d_model + (size_t)s.ev * 6 * NS;
         j.model8 = a->d_model8 + (size_t)s.ev * (MODEL_ROW_BYTES / 8) * NS;
         j.lev[0] = a->d_lev[0] + 4 * a->off[s.ev]; j.lev[1] = a->d_lev[1] + 4 * a->off[s.ev];
         if (!a->fastdiv) d.fastdiv = 0;

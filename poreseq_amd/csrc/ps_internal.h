@@ -94,11 +94,9 @@ struct Runtime {
     template <class T> int down(T** hptr, const void* src, size_t count) { return down((void**)hptr, src, count * sizeof(T)); }
 };
 int runtime(Runtime** out);  // PS_ERR_NO_DEVICE when no usable GPU; never falls back
-// The stream Smith-Waterman batches should use: the runtime's second stream (created on first use), so that the
-// batch overlaps with the base realign of FindMutations — unless PORESEQ_ONE_STREAM is set, which a driver does when
-// it keeps more than ~10 regions in flight on one GPU: with that many host threads the hardware queues are
-// oversubscribed by second streams (measured: 10 concurrent regions with two streams each run at full speed, 11 fall
-// off a cliff, 16-20 regions with one stream each are fine), and the overlap comes from the other regions anyway.
+// The stream Smith-Waterman batches should use: the runtime's second stream (created on first use), so that the batch overlaps with
+// the base realign of FindMutations — while the calling thread is the only one inside the library.  With several threads (lock-step
+// batches in flight) every runtime keeps to one stream: HIP maps streams onto 4 hardware queues by default (ps_host.cpp).
 int second_stream(Runtime* rt, hipStream_t* out);
 
 // ---- mutation list (vector<MutInfo>/vector<MutScore>, cpp/AlignUtil.h:69-91) ----------------
@@ -113,11 +111,7 @@ struct Mut {
 // AlignData's slab), so one batch can mix jobs of several AlignData handles (regions refined in lock-step).
 struct JobOut;
 struct JobD {
-    const double* mean;   // levels of the job's event  [n0]
-    const double* stdv;
-    const double* lsd;    // log(stdv), host libm
-    const double* model;  // derived model of the event, [6][1024]: lev_mean, lev_stdv, log_lev, sd_mean, sd_lambda, log_lambda
-    const double* model8; // the same per 5-mer, rows of MODEL_ROW_BYTES: mean, 1/stdv, stdv, log stdv, sd mean, 1/sd mean, lambda, log lambda (k_fill)
+    const double* model8; // derived model of the job's event per 5-mer, rows of MODEL_ROW_BYTES: mean, 1/stdv, stdv, log stdv, sd mean, 1/sd mean, lambda, log lambda (k_fill)
     const double* lev[2]; // level records per direction, [n0][4]: forward row i -> {mean[i-1], stdv[i-1], 3 lsd[n0-i], 1/stdv[i-1]},
                           //                                      backward row i -> the same of level n0-i (cpp/Alignment.cpp:171-172, 345-349)
     const int* st;        // 5-mer states of the job's sequence [C] (4 ints of -1 padding on either side)
@@ -127,7 +121,7 @@ struct JobD {
     int C;           // states of the job's sequence
     int W;           // realign_width (band half-width of the fills)
     int force_inert; // realign_width == 0: every Alignment is a no-op (cpp/Alignment.cpp:85-86)
-    int P;           // slots per anti-diagonal (multiple of 64, >= widest footprint + 5)
+    int P;           // slots per anti-diagonal (multiple of 64, >= widest footprint + 9; k_fill_wide: multiple of 128, >= footprint + 2)
     int lbn;         // entries in each lb table (C + 2 + extra)
     int pad0, pad1;
     int64_t lb_off;      // lb table the fills were made with          (int32[lbn])

@@ -59,18 +59,6 @@ __device__ __forceinline__ void band_of(const int* __restrict__ lb, int dir, int
 
 __device__ __forceinline__ int slot_of(int i, int P) { return i % P; }
 
-// emission log-density; cpp/AlignUtil.h:34-38,48-53 + cpp/Alignment.cpp:169-173
-struct ModelRow { double mu, sg, lsg, sm, lam, llam; };
-__device__ __forceinline__ double emission(const ModelRow& m, double x, double sd, double lsd, double log2pi, double off) {
-    double d = (x - m.mu) / m.sg;
-    double l = -0.5 * (d * d + log2pi) - m.lsg;
-    double e = (sd - m.sm) / m.sm;
-    double g = 0.5 * (m.llam - 3 * lsd - log2pi - e * e * m.lam / sd);
-    l += g;
-    l += off;
-    return l;
-}
-
 // ------------------------------------------------------------------------------------------------
 // updaterefs: ref_align -> ref_index, refstart, refend   (cpp/EventData.h:110-169)
 // one 256-thread block per job; each thread owns a contiguous chunk of levels
