@@ -490,6 +490,7 @@ int realign(Runtime* rt, Batch& b) {
     if (std::max(*w, 1) + 2 > 2048)
         return fail(PS_ERR_UNSUPPORTED, "band footprint of " + std::to_string(*w) + " rows on one anti-diagonal: wider than two slots per lane of one "
                                         "workgroup (2046); realign_width up to 1022 fits for any input");
+    { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign: %d jobs x %d, widest footprint %d\n", b.d.njobs, b.ndir, *w); }
     PS_TRY(b.place(rt, std::max(*w, 1) + 9 <= 1024 ? std::max(*w, 1) + 9 : ((std::max(*w, 1) + 2 + 127) / 128) * 128));
     if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs * b.ndir; }
     PS_TRY(launch_fill(rt, b.d, b.jobs, b.ndir, b.maxS, b.P, b.ncols));

@@ -231,6 +231,23 @@ def test_edge_cases_match_oracle():
         B.make_pa(PSAlign, draft, copy.deepcopy(events), P0).ScoreMutations([m])
 
 
+def test_mutate_with_unalignable_and_duplicate_seeds_matches_oracle():
+    """explicit seed lists: a seed that does not align at all (its events get no ref_index: inert sweeps next to live ones in one
+    workgroup pair), the same seed twice (likelihood cache), an odd number of seeds (an unpaired sweep)"""
+    draft, events, truth = synth.make_region(500, 6, 501, B.oracle_swalign, P0)
+    rng = np.random.default_rng(9)
+    seeds = [truth, "ACGT" * 6, synth.corrupt(rng, truth, 0.03, 0.03, 0.03), truth, synth.random_sequence(rng, 300)]
+    seeds += [synth.corrupt(rng, truth, 0.02, 0.02, 0.02) for _ in range(22)]      # 27 distinct-ish seeds x 6 events = 162 sweeps: paired workgroups
+    res = []
+    for cls in (PSAlign, B.OraclePSAlign):
+        pa = B.make_pa(cls, draft, copy.deepcopy(events), P0)
+        nb = pa.Mutate(seqs=list(seeds), reps=3)
+        res.append((nb, pa.sequence, [ev.ref_align.copy() for ev in pa.events], [ev.ref_like.copy() for ev in pa.events]))
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    for x, y in zip(res[0][2] + res[0][3], res[1][2] + res[1][3]):
+        assert np.array_equal(x, y)
+
+
 def test_tiny_sequences_match_oracle():
     """sequences of 5 .. 40 bases (1 .. 36 states; fewer states than the four-state prefetch window of k_fill)"""
     for L, seed in ((5, 1), (6, 2), (8, 3), (12, 4), (40, 5)):
