@@ -327,8 +327,10 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     pairs.assign(np, SwPair());
     int maxn2 = 1;
     for (int k = 0; k < np; k++) maxn2 = std::max(maxn2, (int)in[k].second->size());
-    // 4 columns per lane (4096 per workgroup) for short pairs, 8 beyond: a 10 kb pair runs on two workgroups / CUs
-    const int K = maxn2 <= 4096 ? 4 : 8;
+    // 4 columns per lane = 2048 per workgroup: a 10 kb pair runs as five chained workgroups, all but the last full (8 columns per
+    // lane: three, the last 44 % used, 7.8 instead of 6.6 ms per pair); PORESEQ_SW_K=8 selects the wide build (tests)
+    int K = 4;
+    if (const char* e = getenv("PORESEQ_SW_K")) K = atoi(e) == 8 ? 8 : 4;
     const int sswidth = SWW * 64 * K;
     const int nss = (maxn2 + sswidth - 1) / sswidth;
     int64_t row_tot = 0, col_tot = 0, blk_tot = 0, out_tot = 0;

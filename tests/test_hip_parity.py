@@ -3,6 +3,7 @@ the same seeded inputs and against the reference's golden vectors.  Integer / in
 is required bit-exact; the only tolerance is on ViterbiMutate's forward probabilities, which feed
 nothing but the stochastic back-traces (checked through the resulting sequences)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -201,10 +202,17 @@ def test_sw_all_strip_widths_and_super_strips_match_oracle():
     cases.append((unit * 60, unit * 130))                       # tandem repeat: ties everywhere
     cases.append((synth.random_sequence(rng, 5000), synth.random_sequence(rng, 5200)))   # unrelated
     cases.append(("ACGT" * 300, "TGCA" * 1100))
-    for s1, s2 in cases:
-        a, b = swalign(s1, s2), B.oracle_swalign(s1, s2)
-        assert a[1] == b[1], (len(s1), len(s2))
-        assert (a[0] == b[0]) or (np.isnan(a[0]) and np.isnan(b[0]))
+    want = [B.oracle_swalign(s1, s2) for s1, s2 in cases]
+    for env in (None, "8"):                      # the default 4-columns-per-lane build and the 8-column one
+        if env:
+            os.environ["PORESEQ_SW_K"] = env
+        try:
+            for (s1, s2), b in zip(cases, want):
+                a = swalign(s1, s2)
+                assert a[1] == b[1], (len(s1), len(s2), env)
+                assert (a[0] == b[0]) or (np.isnan(a[0]) and np.isnan(b[0]))
+        finally:
+            os.environ.pop("PORESEQ_SW_K", None)
 
 
 def test_edge_cases_match_oracle():
