@@ -225,6 +225,28 @@ __device__ __forceinline__ double wave_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// one bit per anti-diagonal of a 64-step chunk (lane k holds lo of step k, `before` = lo of the step before the chunk): the
+// band resumes there after an empty stretch (lo(t-1) < 0 <= lo(t))
+__device__ __forceinline__ unsigned long long resume_bits(int lov, int before) {
+    const int prev = __builtin_amdgcn_update_dpp(before, lov, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    return __ballot(lov >= 0 && prev < 0);
+}
+// Which 8-step bodies must run k_fill's SLOW variant because of the resumes `rm` of one chunk: a resume on anti-diagonal t makes
+// every body holding a step of [t - 6, t + 6] slow, i.e. a body starting at s0 is slow for a resume in [s0 - 6, s0 + 13].
+// bit 7: the last body of the chunk before, bits 8-15: the chunk's own bodies, bit 16: the first body of the chunk after
+__device__ __forceinline__ unsigned resume_spread(unsigned long long rm) {
+    if (!rm) return 0u;
+    unsigned r = (rm & 0x3Full) ? 0x80u : 0u;
+    r |= (rm >> 58) ? 0x10000u : 0u;
+#pragma unroll
+    for (int bd = 0; bd < 8; bd++) {
+        const int a = 8 * bd - 6;
+        const unsigned long long w = a < 0 ? (0xFFFFFull >> -a) : (0xFFFFFull << a);
+        r |= (rm & w) ? (0x100u << bd) : 0u;
+    }
+    return r;
+}
+
 constexpr int FB = 8;            // anti-diagonals per loop body
 constexpr int FCH = 64;          // anti-diagonals per chunk: lo / hi prefetch unit, flush interval of the column maxima
 
@@ -306,13 +328,25 @@ __device__ __forceinline__ double fill_emission(const FillCtx& c, const double (
     return emission8<FASTDIV>(m, lev, c.log2pi, c.off);
 }
 
+// Model rows in LDS, two layouts:
+//  * 80 bytes apart (the host's layout, copied as is).  With 64 the k-th quarter of every row falls on 4 of the 16 four-bank
+//    groups (ds_read_b128 of 64 random rows: 71 % conflict cycles measured), with 80 on all 16.
+//  * CMP (compact): 64 bytes apart, quarter k of row r stored in quarter k ^ ((r >> 2) & 3) — the same 16 groups in 64 KB
+//    instead of 80, at 5 more VALU instructions per step.  With it a lone sweep of up to 384 lanes (256 backward) takes
+//    at most half of a CU's 160 KB of LDS, so two workgroups share a CU.
+template <bool CMP>
 __device__ __forceinline__ void fill_model_row(const FillCtx& c, int state, double (&m)[8]) {
-    // rows are 80 bytes apart: with 64 the k-th quarter of every row falls on 4 of the 16 four-bank groups (ds_read_b128 of 64
-    // random rows: 71 % conflict cycles measured), with 80 on all 16
     static_assert(MODEL_ROW_BYTES == 80, "row address below is state * 64 + state * 16");
     const int st0 = state < 0 ? 0 : state;
-    const char* row = c.mdl + ((st0 << 6) + (st0 << 4));
-    const double2 a = *(const double2*)row, bq = *(const double2*)(row + 16), cq = *(const double2*)(row + 32), dq = *(const double2*)(row + 48);
+    double2 a, bq, cq, dq;
+    if (CMP) {
+        const unsigned q0 = ((unsigned)st0 << 6) | (((unsigned)st0 << 2) & 0x30u);
+        a = *(const double2*)(c.mdl + q0); bq = *(const double2*)(c.mdl + (q0 ^ 16u));
+        cq = *(const double2*)(c.mdl + (q0 ^ 32u)); dq = *(const double2*)(c.mdl + (q0 ^ 48u));
+    } else {
+        const char* row = c.mdl + ((st0 << 6) + (st0 << 4));
+        a = *(const double2*)row; bq = *(const double2*)(row + 16); cq = *(const double2*)(row + 32); dq = *(const double2*)(row + 48);
+    }
     m[0] = a.x; m[1] = a.y; m[2] = bq.x; m[3] = bq.y; m[4] = cq.x; m[5] = cq.y; m[6] = dq.x; m[7] = dq.y;
 }
 
@@ -336,7 +370,7 @@ __device__ __forceinline__ int fill_row_of(const FillCtx& c, int lo) {
 }
 
 // One anti-diagonal.  PH = position in the loop body (compile time): exchange buffer, window set, state queue slot.
-template <int DIR, int PH, bool SLOW, bool FASTDIV>
+template <int DIR, int PH, bool SLOW, bool FASTDIV, bool CMP>
 __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, const int s, const int lo_s, const int hi_s,
                                           const bool newcol /* uniform: a column starts on this anti-diagonal */) {
     const double NINF = -__builtin_inf();
@@ -401,7 +435,7 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
             state = c.st[fill_state_index<DIR>(c, s + 3, lo3 >= 0 ? fill_row_of(c, lo3) : i)];
         }
         r.stq[(PH + 3) & 3] = state;
-        fill_model_row(c, state, r.mr);
+        fill_model_row<CMP>(c, state, r.mr);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- recurrence on anti-diagonal s
@@ -466,17 +500,17 @@ __device__ __forceinline__ void fill_step(FillState<DIR>& r, const FillCtx& c, c
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int DIR, bool SLOW, bool FASTDIV>
+template <int DIR, bool SLOW, bool FASTDIV, bool CMP>
 __device__ __forceinline__ void fill_group8(FillState<DIR>& r, const FillCtx& c, const int s0, const int (&lov)[FB], const int (&hiv)[FB], const int lo_p) {
 #define PS_NEWCOL(k, prev) ((prev) < 0 || lov[k] == (prev))
-    fill_step<DIR, 0, SLOW, FASTDIV>(r, c, s0 + 0, lov[0], hiv[0], PS_NEWCOL(0, lo_p));
-    fill_step<DIR, 1, SLOW, FASTDIV>(r, c, s0 + 1, lov[1], hiv[1], PS_NEWCOL(1, lov[0]));
-    fill_step<DIR, 2, SLOW, FASTDIV>(r, c, s0 + 2, lov[2], hiv[2], PS_NEWCOL(2, lov[1]));
-    fill_step<DIR, 3, SLOW, FASTDIV>(r, c, s0 + 3, lov[3], hiv[3], PS_NEWCOL(3, lov[2]));
-    fill_step<DIR, 4, SLOW, FASTDIV>(r, c, s0 + 4, lov[4], hiv[4], PS_NEWCOL(4, lov[3]));
-    fill_step<DIR, 5, SLOW, FASTDIV>(r, c, s0 + 5, lov[5], hiv[5], PS_NEWCOL(5, lov[4]));
-    fill_step<DIR, 6, SLOW, FASTDIV>(r, c, s0 + 6, lov[6], hiv[6], PS_NEWCOL(6, lov[5]));
-    fill_step<DIR, 7, SLOW, FASTDIV>(r, c, s0 + 7, lov[7], hiv[7], PS_NEWCOL(7, lov[6]));
+    fill_step<DIR, 0, SLOW, FASTDIV, CMP>(r, c, s0 + 0, lov[0], hiv[0], PS_NEWCOL(0, lo_p));
+    fill_step<DIR, 1, SLOW, FASTDIV, CMP>(r, c, s0 + 1, lov[1], hiv[1], PS_NEWCOL(1, lov[0]));
+    fill_step<DIR, 2, SLOW, FASTDIV, CMP>(r, c, s0 + 2, lov[2], hiv[2], PS_NEWCOL(2, lov[1]));
+    fill_step<DIR, 3, SLOW, FASTDIV, CMP>(r, c, s0 + 3, lov[3], hiv[3], PS_NEWCOL(3, lov[2]));
+    fill_step<DIR, 4, SLOW, FASTDIV, CMP>(r, c, s0 + 4, lov[4], hiv[4], PS_NEWCOL(4, lov[3]));
+    fill_step<DIR, 5, SLOW, FASTDIV, CMP>(r, c, s0 + 5, lov[5], hiv[5], PS_NEWCOL(5, lov[4]));
+    fill_step<DIR, 6, SLOW, FASTDIV, CMP>(r, c, s0 + 6, lov[6], hiv[6], PS_NEWCOL(6, lov[5]));
+    fill_step<DIR, 7, SLOW, FASTDIV, CMP>(r, c, s0 + 7, lov[7], hiv[7], PS_NEWCOL(7, lov[6]));
 #undef PS_NEWCOL
 }
 
@@ -485,7 +519,7 @@ constexpr int FILL_MODEL_BYTES = MODEL_ROW_BYTES * NS;
 // One half of a k_fill workgroup: the sweep of one (job, direction).  `slot` is the thread's lane inside the half, `hsm` the
 // half's private LDS (exchange buffers, ring, bitmap), `model` the workgroup's shared model rows, Smax the longer of the two
 // sweeps of the workgroup (both halves execute the same number of barriers).
-template <int DIR, bool FASTDIV>
+template <int DIR, bool FASTDIV, bool CMP>
 __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const char* model, char* hsm, const int slot, const int Smax,
                                           const int rcols, const int slowwords) {
     const int P = uni(J.P);
@@ -499,11 +533,11 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const 
     constexpr int RB = DIR ? 24 : 16;   // bytes per exchanged record: {main, stay} / {main, stay + em, main + em}
     c.mdl = model;
     c.xch = hsm;
-    c.ring = c.xch + 2 * P * 24;
+    c.ring = c.xch + 2 * P * (CMP ? RB : 24);   // (a half of a pair may run either direction: sized for the larger record)
     c.ringmask = (unsigned)rcols * 8u - 1u;
-    unsigned* slowmap = (unsigned*)(c.ring + rcols * 8);
+    unsigned* slowmap = (unsigned*)(c.ring + rcols * 8);   // (!CMP) one bit per 8-step body: it runs the SLOW variant
     for (int k = slot; k < rcols; k += P) ((unsigned long long*)c.ring)[k] = 0ull;
-    for (int k = slot; k < slowwords; k += P) slowmap[k] = 0u;
+    if (!CMP) for (int k = slot; k < slowwords; k += P) slowmap[k] = 0u;
     const int up_slot = slot == 0 ? P - 1 : slot - 1;
     const double NINF = -__builtin_inf();
 #pragma unroll
@@ -517,14 +551,18 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const 
     const int s_first = 2 - FB;                          // the pipeline needs a few steps to fill; they fall into the front padding
     c.S = S;
     __syncthreads();
-    // bodies that must run the SLOW variant: the band resumes on anti-diagonal t (lo(t-1) < 0 <= lo(t)).  Windows fetched on
-    // t - 9 .. t - 1 hold the states / levels of rows that may no longer be the lane's; they are consumed on t - 6 .. t + 6
-    for (int t = 2 + slot; t < S; t += P) {
-        if (c.LO[t] >= 0 && c.LO[t - 1] < 0) {
-            const int b0 = max(0, (t - 6 - s_first) >> 3), b1 = (t + 6 - s_first) >> 3;
-            for (int bb = b0; bb <= b1; bb++) atomicOr(&slowmap[bb >> 5], 1u << (bb & 31));
+    // Bodies that must run the SLOW variant: the band resumes on anti-diagonal t (lo(t-1) < 0 <= lo(t)).  Windows fetched on
+    // t - 9 .. t - 1 hold the states / levels of rows that may no longer be the lane's; they are consumed on t - 6 .. t + 6:
+    // every body holding a step of [t - 6, t + 6] is slow.  The plain layout marks them in an LDS bitmap up front; the compact
+    // one has no LDS to spare and derives them from the lo chunks as they stream by (resume_spread).  (One mechanism would do,
+    // but the second costs the 168-VGPR pair build 70 spilled registers and 4 % — register allocation, not logic.)
+    if (!CMP)
+        for (int t = 2 + slot; t < S; t += P) {
+            if (c.LO[t] >= 0 && c.LO[t - 1] < 0) {
+                const int b0 = max(0, (t - 6 - s_first) >> 3), b1 = (t + 6 - s_first) >> 3;
+                for (int bb = b0; bb <= b1; bb++) atomicOr(&slowmap[bb >> 5], 1u << (bb & 31));
+            }
         }
-    }
     FillState<DIR> r;
     r.cm = NINF; r.cs = NINF; r.dm = NINF; r.de = NINF; r.o1 = 0.0; r.o2 = 0.0;
     r.pin = false; r.ptop = false; r.pdead = false;
@@ -547,21 +585,25 @@ __device__ __forceinline__ void fill_body(const BatchD& b, const JobD& J, const 
     // lo / hi of 64 anti-diagonals per VGPR (lane k holds entry k), fetched one chunk ahead
     int loc = c.LO[max(s_first + lane, 0)], hic = c.HI[max(s_first + lane, 0)];
     if (s_first + lane < 0) { loc = -1; hic = -1; }
+    // `slow` (CMP): bits 0-7 the bodies of the current chunk, above them what is known of the chunks after (one scalar register)
+    unsigned slow = CMP ? __builtin_amdgcn_readfirstlane(resume_spread(resume_bits(loc, -1)) >> 8) : 0u;
     int nbody = 0;
     for (int cb = s_first; cb < Smax; cb += FCH) {
         const int lon = c.LO[min(cb + FCH + lane, S + LO_PAD - 1)], hin = c.HI[min(cb + FCH + lane, S + LO_PAD - 1)];
+        if (CMP) slow |= __builtin_amdgcn_readfirstlane(resume_spread(resume_bits(lon, __builtin_amdgcn_readlane(loc, 63))));
 #pragma unroll 1
         for (int o = 0; o < FCH && cb + o < Smax; o += FB, nbody++) {
             const int s0 = cb + o;
             int lov[FB], hiv[FB];
 #pragma unroll
             for (int k = 0; k < FB; k++) { lov[k] = __builtin_amdgcn_readlane(loc, o + k); hiv[k] = __builtin_amdgcn_readlane(hic, o + k); }
-            const unsigned sw = __builtin_amdgcn_readfirstlane(slowmap[nbody >> 5]);
-            if ((sw >> (nbody & 31)) & 1u) fill_group8<DIR, true, FASTDIV>(r, c, s0, lov, hiv, lo_p);
-            else fill_group8<DIR, false, FASTDIV>(r, c, s0, lov, hiv, lo_p);
+            const unsigned sw = CMP ? slow >> (o >> 3) : __builtin_amdgcn_readfirstlane(slowmap[nbody >> 5]) >> (nbody & 31);
+            if (sw & 1u) fill_group8<DIR, true, FASTDIV, CMP>(r, c, s0, lov, hiv, lo_p);
+            else fill_group8<DIR, false, FASTDIV, CMP>(r, c, s0, lov, hiv, lo_p);
             lo_p = lov[FB - 1];
         }
         loc = lon; hic = hin;
+        slow >>= 8;
         // flush the maxima of completed columns: every column left of the oldest one still present on the next anti-diagonal
         {
             const int sn = cb + FCH;
@@ -747,27 +789,36 @@ __device__ __forceinline__ void fill_idle(const int Smax) {
 // by the other two (a lone sweep's 5-6 waves leave one SIMD with two waves and the others waiting for it).
 // pairs[2 * blockIdx.x + h] = job * ndir + dir of half h, or -1.  PAIR = false: one sweep per workgroup (P > 384).
 // FASTDIV: tabulated reciprocals (the normal case) or IEEE divisions (some divisor of the AlignData is not a sane number)
-template <int MAXT, bool PAIR, bool FASTDIV>
+template <int MAXT, bool PAIR, bool FASTDIV, bool CMP>
 __global__ __launch_bounds__(MAXT) void k_fill(BatchD b, const int* __restrict__ pairs, int ndir, int P, int rcols, int slowwords, int halfbytes) {
+    static_assert(!(PAIR && CMP), "the compact layout is for lone sweeps");
     extern __shared__ double2 fill_smem[];
     char* smem = (char*)fill_smem;
+    constexpr int MODEL_LDS = CMP ? 64 * NS : FILL_MODEL_BYTES;
     const int hw = PAIR ? (int)threadIdx.x / P : 0;
     const int slot = (int)threadIdx.x - hw * P;
     const int jdA = pairs[2 * blockIdx.x], jdB = PAIR ? pairs[2 * blockIdx.x + 1] : -1;
     const bool okA = jdA >= 0 && !b.jobs[jdA / ndir].out->inert, okB = jdB >= 0 && !b.jobs[jdB / ndir].out->inert;
     if (!okA && !okB) return;
     const int Smax = max(okA ? (int)b.jobs[jdA / ndir].S : 0, okB ? (int)b.jobs[jdB / ndir].S : 0);
-    {   // the event's model rows (64 bytes per 5-mer, laid out by the host): one copy for the workgroup
+    {   // the event's model rows (laid out by the host, 80 bytes apart): one copy for the workgroup
         const double2* src = (const double2*)b.jobs[(okA ? jdA : jdB) / ndir].model8;
         double2* dst = (double2*)smem;
-        for (int k = threadIdx.x; k < FILL_MODEL_BYTES / 16; k += blockDim.x) dst[k] = src[k];
+        if (CMP) {
+            for (int k = threadIdx.x; k < 4 * NS; k += blockDim.x) {
+                const int row = k >> 2, q = k & 3;
+                dst[(row << 2) | (q ^ ((row >> 2) & 3))] = src[row * 5 + q];
+            }
+        } else {
+            for (int k = threadIdx.x; k < FILL_MODEL_BYTES / 16; k += blockDim.x) dst[k] = src[k];
+        }
     }
     const int jd = hw == 0 ? jdA : jdB;
     if (!(hw == 0 ? okA : okB)) { fill_idle(Smax); return; }
     const JobD& J = b.jobs[jd / ndir];
-    char* hsm = smem + FILL_MODEL_BYTES + hw * halfbytes;
-    if (jd % ndir == 0) fill_body<0, FASTDIV>(b, J, smem, hsm, slot, Smax, rcols, slowwords);
-    else fill_body<1, FASTDIV>(b, J, smem, hsm, slot, Smax, rcols, slowwords);
+    char* hsm = smem + MODEL_LDS + hw * halfbytes;
+    if (jd % ndir == 0) fill_body<0, FASTDIV, CMP>(b, J, smem, hsm, slot, Smax, rcols, slowwords);
+    else fill_body<1, FASTDIV, CMP>(b, J, smem, hsm, slot, Smax, rcols, slowwords);
 }
 
 // prefix max over columns + (fwd) the first cell achieving the global max ; grid njobs*ndir, block 64
@@ -1272,19 +1323,22 @@ int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS) {
 }
 
 constexpr int PAIR_MIN_SWEEPS = 160;
-// LDS of one k_fill workgroup: the event's model rows (64 KB) + per half two exchange buffers, the column-maxima ring, the slow-body bitmap
+// LDS of one k_fill workgroup: the event's model rows + per half two exchange buffers, the column-maxima ring, the slow-body bitmap
 static int fill_ring_cols(int P) { return P + 96 <= 512 ? 512 : (P + 96 <= 1024 ? 1024 : 2048); }
 static int fill_slow_words(int64_t maxS) { return (int)((maxS + 2 * FB) / FB / 32 + 2); }
 static int fill_half_bytes(int P, int64_t maxS) {
     return (int)((((size_t)2 * P * 24 + (size_t)fill_ring_cols(P) * 8 + (size_t)fill_slow_words(maxS) * 4) + 63) / 64 * 64);
 }
+// compact layout (lone sweeps): 64 KB of model rows, exchange records sized for the widest direction present
+static int fill_compact_bytes(int P, int ndir) { return 64 * NS + 2 * P * (ndir == 2 ? 24 : 16) + fill_ring_cols(P) * 8; }
+constexpr int LDS_HALF_CU = 80 * 1024;
 
-template <int MAXT, bool PAIR>
+template <int MAXT, bool PAIR, bool CMP>
 static void fill_launch(Runtime* rt, const BatchD& b, const int* d_pairs, int nwg, int ndir, int P, int64_t maxS, size_t lds) {
     const dim3 grid(nwg), block(PAIR ? 2 * P : P);
     const int rc = fill_ring_cols(P), sw = fill_slow_words(maxS), hb = fill_half_bytes(P, maxS);
-    if (b.fastdiv) hipLaunchKernelGGL((k_fill<MAXT, PAIR, true>), grid, block, lds, rt->stream, b, d_pairs, ndir, P, rc, sw, hb);
-    else hipLaunchKernelGGL((k_fill<MAXT, PAIR, false>), grid, block, lds, rt->stream, b, d_pairs, ndir, P, rc, sw, hb);
+    if (b.fastdiv) hipLaunchKernelGGL((k_fill<MAXT, PAIR, true, CMP>), grid, block, lds, rt->stream, b, d_pairs, ndir, P, rc, sw, hb);
+    else hipLaunchKernelGGL((k_fill<MAXT, PAIR, false, CMP>), grid, block, lds, rt->stream, b, d_pairs, ndir, P, rc, sw, hb);
 }
 
 int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int ndir, int64_t maxS, int P, int64_t ncols) {
@@ -1292,9 +1346,10 @@ int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int
     static bool attr_set = false;   // more than the default 64 KB of dynamic LDS needs the attribute (idempotent; racing threads set the same value)
     if (!attr_set) {
 #define PS_FILL_ATTR(...) PS_HIP(hipFuncSetAttribute((const void*)k_fill<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        PS_FILL_ATTR(768, true, true); PS_FILL_ATTR(768, true, false);
-        PS_FILL_ATTR(512, false, true); PS_FILL_ATTR(512, false, false);
-        PS_FILL_ATTR(1024, false, true); PS_FILL_ATTR(1024, false, false);
+        PS_FILL_ATTR(768, true, true, false); PS_FILL_ATTR(768, true, false, false);
+        PS_FILL_ATTR(512, false, true, false); PS_FILL_ATTR(512, false, false, false);
+        PS_FILL_ATTR(512, false, true, true); PS_FILL_ATTR(512, false, false, true);
+        PS_FILL_ATTR(1024, false, true, false); PS_FILL_ATTR(1024, false, false, false);
 #undef PS_FILL_ATTR
         attr_set = true;
     }
@@ -1321,31 +1376,42 @@ int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int
     // forward-only jobs of one event (candidate sequences of FindMutations), longest with longest
     // (a launch that fits the chip with one sweep per workgroup keeps them apart: a lone sweep finishes ~20 % sooner than a pair,
     //  and a launch this small is on some region's critical path)
-    const bool pair = 2 * P <= 768 && b.njobs * ndir > PAIR_MIN_SWEEPS;
+    static const int pair_min = getenv("PORESEQ_DEBUG_PAIR_MIN") ? atoi(getenv("PORESEQ_DEBUG_PAIR_MIN")) : PAIR_MIN_SWEEPS;   // (tuning probes)
+    bool pair = 2 * P <= 768 && b.njobs * ndir > pair_min;
     std::vector<int> pr;
     if (pair && ndir == 2) {
         for (int j = 0; j < b.njobs; j++) { pr.push_back(2 * j); pr.push_back(2 * j + 1); }
     } else if (pair) {
         std::map<const double*, std::vector<int>> by_event;
         for (int j = 0; j < b.njobs; j++) by_event[jobs[j].model8].push_back(j);
+        bool any = false;
+        for (auto& kv : by_event) any |= kv.second.size() > 1;
+        if (!any) pair = false;   // every event appears once (forward sweeps of many regions): nothing to share a table with
         for (auto& kv : by_event) {
+            if (!pair) break;
             std::vector<int>& v = kv.second;
             std::sort(v.begin(), v.end(), [&](int x, int y) { return jobs[x].S != jobs[y].S ? jobs[x].S > jobs[y].S : x < y; });
             for (size_t k = 0; k < v.size(); k += 2) { pr.push_back(v[k]); pr.push_back(k + 1 < v.size() ? v[k + 1] : -1); }
         }
-    } else {
-        for (int jd = 0; jd < b.njobs * ndir; jd++) { pr.push_back(jd); pr.push_back(-1); }
     }
+    if (!pair)
+        for (int jd = 0; jd < b.njobs * ndir; jd++) { pr.push_back(jd); pr.push_back(-1); }
     const int nwg = (int)pr.size() / 2;
     PS_TRY(rt->buf("fill_pairs").ensure(pr.size() * sizeof(int)));
     int* d_pairs = rt->buf("fill_pairs").as<int>();
     PS_TRY(rt->up(d_pairs, pr.data(), pr.size() * sizeof(int)));
-    const size_t lds = FILL_MODEL_BYTES + (size_t)(pair ? 2 : 1) * fill_half_bytes(P, maxS);
+    // a lone sweep of up to four waves takes the compact layout: two workgroups per CU (one wave of each per SIMD; measured
+    // 1.5x the sweeps per second of one workgroup per CU at P = 192).  Wider ones stay alone on their CU whatever the LDS says:
+    // five or six waves put two on SIMD 0, and a second workgroup's two more do not fit there beside them at 200 VGPRs
+    // (tried at 168 VGPRs and exactly 80 KB for P = 384: no co-residency, and 10 % slower for the spills).
+    const bool compact = !pair && P <= 256 && fill_compact_bytes(P, ndir) <= LDS_HALF_CU;
+    const size_t lds = compact ? fill_compact_bytes(P, ndir) : FILL_MODEL_BYTES + (size_t)(pair ? 2 : 1) * fill_half_bytes(P, maxS);
     if (lds > 160 * 1024) return fail(PS_ERR_UNSUPPORTED, "alignment too long for the fill kernel's LDS bitmap");
     prof_begin(rt);
-    if (pair) fill_launch<768, true>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
-    else if (P <= 512) fill_launch<512, false>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
-    else fill_launch<1024, false>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
+    if (pair) fill_launch<768, true, false>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
+    else if (compact) fill_launch<512, false, true>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
+    else if (P <= 512) fill_launch<512, false, false>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
+    else fill_launch<1024, false, false>(rt, b, d_pairs, nwg, ndir, P, maxS, lds);
     PS_LAUNCH_CHECK();
     prof_end(rt, "fill", 0.0);
     hipLaunchKernelGGL(k_prefix, dim3(b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
