@@ -4,9 +4,10 @@
 One "step" = the full `poreseq consensus` schedule (Mutate('self') then up to 4 x {Mutate('viterbi'), Refine()},
 poreseq/Mutate.py:70-85) over one BATCH of R independent synthetic regions, each 10 kb with 10 event streams
 (BASELINE.json configs[1]), through the drop-in API and the C ABI.  Regions are the reference's own unit of
-parallelism (one process per region file, README.md:48-54).  One GPU refines the R regions of a step in LOCK-STEP from
-one host thread (poreseq_amd.batch / the ps_batch_* entry points): every phase of the schedule is one launch chain over
-all regions' events, with the default HIP environment (no extra hardware queues, no per-region threads or streams).
+parallelism (one process per region file, README.md:48-54).  One GPU refines the R regions of a step as B lock-step
+batches (poreseq_amd.batch / the ps_batch_* entry points; one host thread and one stream per batch): every phase of the
+schedule is one launch chain over all of a batch's events, with the default HIP environment (no extra hardware queues,
+no per-region threads or streams).  Default: 96 regions as 6 batches of 16.
 The events of a step's regions are resident in HBM when the clock starts (RegionBatch.load: the marshalling + H2D copy
 a PSAlign call would do); DESIGN.md section 7 gives the PCIe-inclusive rate.  With N GPUs every rank refines its own
 batch per step (weak scaling, no data-path collective) and the value is the whole-job rate
@@ -17,10 +18,10 @@ N * R * region_kb * K / max-over-ranks time.
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 with
-  roofline        the dominant kernel class (HIP-event time on the library's stream in a separate profiled step of the
-                  same batch): algorithmic bytes per launch / average launch duration against the HBM peak; `traffic`
-                  from the committed rocprofv3 PMC measurement of the same command (profiles/, tools/pmc_bench.sh),
-                  refused when its launch shape disagrees with the live pass
+  roofline        the dominant kernel class: HIP events around every launch on the launching stream INSIDE the timed steps
+                  (queued, read after each host thread's work): algorithmic bytes per launch / average launch duration
+                  against the HBM peak; `traffic` from the committed rocprofv3 PMC measurement of the same command
+                  (profiles/, tools/pmc_bench.sh), refused when its launch shape disagrees with the live measurement
   north_star_1kb  1 kb / 10x: one region alone, a lock-step batch, and the reference C++ at the same size
   cpu_baseline    the reference's C++ (oracle/_ref; the oracle restatement when that is not built) on the host cores:
                   one thread, one process per core, and a same-size (10 kb) extrapolation from measured unit costs
@@ -95,8 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--events", type=int, default=10)
-    ap.add_argument("--regions-per-gpu", type=int, default=64, help="independent regions refined on one GPU per step")
-    ap.add_argument("--batches-in-flight", type=int, default=4,
+    ap.add_argument("--regions-per-gpu", type=int, default=96, help="independent regions refined on one GPU per step")
+    ap.add_argument("--batches-in-flight", type=int, default=6,
                     help="lock-step batches per GPU (one host thread each): while one batch is in a thin phase or on the host, "
                          "the others keep the GPU full; the regions of a step are dealt round-robin to the batches")
     ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")
@@ -138,6 +139,8 @@ def main():
         pa.sequence, pa.events, pa.params = region[0], copy.deepcopy(region[1]), dict(params)
         return pa
 
+    live_prof = []   # per timed step: {class: [ms, launches, bytes, units]} summed over the step's host threads
+
     def run_batch(regs, timed=False, nb=1):
         """one step: the regions dealt to `nb` lock-step batches, one host thread each; the clock (when timed) starts with
         every batch's events resident in HBM"""
@@ -155,9 +158,17 @@ def main():
             except Exception as e:   # pragma: no cover
                 errs.append(e)
 
+        profs = [None] * nb
+
         def work(k):
             try:
+                if timed:            # HIP events around every hot-kernel launch on this thread's stream, read after the work
+                    api.prof_reset()
+                    api.prof_enable(2)
                 outs[k] = consensus_regions(pas[k], params, batch=rbs[k])
+                if timed:
+                    profs[k] = {c: list(api.prof_get(c)) + [api.prof_units(c)] for c in KERNEL_OF}
+                    api.prof_enable(0)
             except Exception as e:   # pragma: no cover
                 errs.append(e)
 
@@ -181,6 +192,8 @@ def main():
         if timed and torch.cuda.is_available():
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if timed:
+            live_prof.append({c: [sum(p[c][i] for p in profs if p) for i in range(4)] for c in KERNEL_OF})
         out = [None] * len(regs)
         for k in range(nb):
             out[k::nb] = outs[k]
@@ -242,21 +255,23 @@ def main():
         out["accuracy"] = {"draft_percent": a0, "consensus_percent": a1}
         out.update(pre)
 
-        if not args.no_extras:
-            # ---- roofline of the dominant kernel class: a separate profiled step of the same batch (HIP events per launch) ----
-            api.prof_reset()
-            api.prof_enable(True)
-            run_batch(regions[-1][:max(1, R // NB)])   # one lock-step batch of the size the timed steps use
-            api.prof_enable(False)
-            prof = {k: api.prof_get(k) for k in KERNEL_OF}
-            dom = max(prof, key=lambda k: prof[k][0])
-            ms, launches, nbytes = prof[dom]
+        sched = None
+        if live_prof:
+            # ---- roofline of the dominant kernel class: HIP events around every launch of the class on the launching stream,
+            #      inside the timed steps (all host threads of this rank; queued, read after each thread's work) ----
+            tot = {c: [sum(lp[c][i] for lp in live_prof) for i in range(4)] for c in KERNEL_OF}
+            dom = max(tot, key=lambda c: tot[c][0])
+            ms, launches, nbytes, units = tot[dom]
             achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": int(launches),
                     "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": nbytes / max(launches, 1),
-                    "sweeps_per_launch": api.prof_units(dom) / max(launches, 1) if dom == "fill" else None,
-                    "all_kernel_classes_ms": {k: v[0] for k, v in prof.items()}}
+                    "sweeps_per_launch": units / max(launches, 1) if dom == "fill" else None,
+                    "measured": "HIP events per launch inside the %d timed step(s), %d launches in flight side by side (one stream per "
+                                "lock-step batch): a launch's duration includes what it shares the chip with" % (args.steps, NB),
+                    "all_kernel_classes_ms_per_step": {c: v[0] / max(args.steps, 1) for c, v in tot.items()}}
+            # aggregate rate of the class over the wall time of the steps (launches of different batches overlap)
+            roof["aggregate_alg_gbs"] = (nbytes / 1e9) / dt if dt > 0 else None
             # HBM-side bytes per launch cannot be collected from inside this process: rocprofv3 --pmc on this very command
             # (tools/pmc_bench.sh) writes profiles/r02_traffic.json; it is used only if its launch shape matches the live pass
             try:
@@ -274,8 +289,7 @@ def main():
             except (OSError, ValueError, KeyError, ZeroDivisionError):
                 pass
             out["roofline"] = roof
-            nprof = max(1, R // NB)
-            sched = {"fill_sweeps": api.prof_units("fill") * R / nprof, "score_items": api.prof_units("score") * R / nprof}
+            sched = {"fill_sweeps": tot["fill"][3] / max(args.steps, 1), "score_items": tot["score"][3] / max(args.steps, 1)}
 
         # ---- parity spot-check + CPU baseline (oracle / reference: checker and baseline only, never the thing measured) ----
         if cpu_pre is not None:

@@ -183,7 +183,9 @@ int ps_debug_fill(ps_align* a, int32_t ev, int32_t direction, double* main, doub
 /* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
  * algorithmic bytes of the named kernel class ("fill", "score", "viterbi", "sw") since reset. */
 /* ps_prof_enable(1) makes every hot-kernel launch be bracketed by HIP events on the library's stream
- * (one extra synchronisation per launch: use it in a separate, untimed pass); ps_prof_reset zeroes the sums. */
+ * (one extra synchronisation per launch: use it in a separate, untimed pass); ps_prof_enable(2) queues the
+ * event pairs instead and reads them when the profile is asked for (no synchronisation per launch: usable
+ * inside a timed region).  The profile belongs to the calling thread's runtime.  ps_prof_reset zeroes the sums. */
 int ps_prof_enable(int32_t on);
 int ps_prof_reset(void);
 int ps_prof_get(const char* name, double* ms, int64_t* launches, double* alg_bytes);

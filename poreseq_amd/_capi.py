@@ -365,7 +365,7 @@ class CApi:
         return main, stay, sm, ss
 
     def prof_enable(self, on):
-        self.check(self.lib.ps_prof_enable(1 if on else 0))
+        self.check(self.lib.ps_prof_enable(int(on)))   # 1: synchronous per launch, 2: event pairs queued and read by prof_get
 
     def prof_reset(self):
         self.check(self.lib.ps_prof_reset())

@@ -303,16 +303,20 @@ int ps_rand_draw(int64_t n, double* out) {
 
 int ps_prof_enable(int32_t on) {
     NEED_RT();
+    prof_flush(rt);
     rt->prof_on = on != 0;
+    rt->prof_defer = on == 2;
     return PS_OK;
 }
 int ps_prof_reset(void) {
     NEED_RT();
+    prof_flush(rt);
     rt->prof.clear();
     return PS_OK;
 }
 int ps_prof_get(const char* name, double* ms, int64_t* n, double* bytes) {
     NEED_RT();
+    prof_flush(rt);
     Prof p;
     if (name) { auto it = rt->prof.find(name); if (it != rt->prof.end()) p = it->second; }
     if (ms) *ms = p.ms;
@@ -323,6 +327,7 @@ int ps_prof_get(const char* name, double* ms, int64_t* n, double* bytes) {
 
 int ps_prof_units(const char* name, double* units) {
     NEED_RT();
+    prof_flush(rt);
     Prof p;
     if (name) { auto it = rt->prof.find(name); if (it != rt->prof.end()) p = it->second; }
     if (units) *units = p.units;

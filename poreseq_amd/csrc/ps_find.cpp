@@ -181,6 +181,8 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
         par_for((int)need.size(), [&](int q) { need[q].states = states_of((*seeds[need[q].r])[need[q].k]); });
         const double cap = max_batch_bytes();
         size_t q0 = 0;
+        int p_seen = 0;   // widest anti-diagonal footprint (in slots) a chunk of this call turned out to need
+        size_t limit = (size_t)-1;   // (region, seed) pairs per chunk after a chunk had to be cut again
         while (q0 < need.size()) {
             // chunk: as many (region, seed) pairs as the matrix budget holds (typical anti-diagonal footprint ~ half the band)
             size_t q1 = q0;
@@ -188,11 +190,11 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
             size_t nref = 0;
             while (q1 < need.size()) {
                 const Align* a = as[need[q1].r];
-                // slots per anti-diagonal as realign will size them: footprint ~ (2W + 1) / 1.9 for about one level per base, + 9
-                const int P = std::min(1024, std::max(64, (((2 * a->par.realign_width + 1) * 10 / 19 + 9 + 63) / 64) * 64));
+                // slots per anti-diagonal as realign will probably size them (the first chunk finds out and is cut again if not)
+                const int P = std::max(p_seen, guess_slots(a));
                 double add = 0;
                 for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + need[q1].states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0;
-                if (q1 > q0 && bytes + add > cap) break;
+                if (q1 > q0 && (bytes + add > cap || q1 - q0 >= limit)) break;
                 bytes += add; nref += (size_t)a->ntot; q1++;
             }
             const size_t stage_mark = rt->stage.mark();
@@ -245,7 +247,19 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
             PS_TRY(b.build(rt, specs, 1, 0));
             PS_TRY(launch_updaterefs(rt, b.d));  // MapAlignments ends with updaterefs (cpp/EventUtil.cpp:51)
             tk.lap("seed batch build");
-            PS_TRY(realign(rt, b));
+            {
+                const int rc = realign(rt, b, q1 - q0 > 1 ? 1.2 * cap : 0.0);
+                if (rc == PS_SPLIT) {   // wider bands than guessed: cut the chunk again with the width it asked for
+                    { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] seed chunk of %zu cut again: %d slots per anti-diagonal, %d guessed\n", q1 - q0, b.P, std::max(p_seen, 0)); }
+                    p_seen = std::max(p_seen, b.P);
+                    limit = std::max<size_t>(1, (q1 - q0) / 2);
+                    PS_HIP(hipStreamSynchronize(rt->stream));
+                    rt->stage.release(stage_mark);
+                    continue;
+                }
+                PS_TRY(rc);
+            }
+            p_seen = std::max(p_seen, b.P);
             double *r_ra = nullptr, *r_rl = nullptr;
             PS_TRY(rt->down(&r_ra, d_ra, nref));
             PS_TRY(rt->down(&r_rl, d_rl, nref));

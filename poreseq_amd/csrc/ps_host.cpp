@@ -34,19 +34,32 @@ void Tick::lap(const char* label) {
 }
 
 // ------------------------------------------------------------------------------------------ runtime
+static size_t trim_idle_runtimes();   // below: hands back the device pools of runtimes no thread owns
+static std::atomic<long long> g_pool_bytes(0);   // device memory held by the pools of all runtimes
+
 int DBuf::ensure(size_t bytes) {
     if (bytes <= cap && p) return PS_OK;
     static const bool trace = getenv("PORESEQ_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[ps] pool grow %zu -> %zu bytes\n", cap, bytes);
-    if (p) { PS_HIP(hipFree(p)); p = nullptr; cap = 0; }
+    if (p) { PS_HIP(hipFree(p)); p = nullptr; g_pool_bytes -= (long long)cap; cap = 0; }
     size_t want = std::max<size_t>(bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30), 1 << 16);   // growth slack, at most 1 GB
     if (hipMalloc(&p, want) != hipSuccess) {
         p = nullptr;
+        (void)hipGetLastError();   // (sticky: the next launch check would report it)
         want = std::max<size_t>(bytes, 1 << 16);
         hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { p = nullptr; return fail(PS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) {
+            // runtimes on the free list (their threads are gone) keep their pools for the next thread: take them back first
+            (void)hipGetLastError();
+            const size_t got = trim_idle_runtimes();
+            if (trace) fprintf(stderr, "[ps] out of device memory: %zu bytes taken back from idle runtimes\n", got);
+            p = nullptr;
+            e = got ? hipMalloc(&p, want) : e;
+        }
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(PS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     }
     cap = want;
+    g_pool_bytes += (long long)cap;
     return PS_OK;
 }
 
@@ -122,8 +135,22 @@ struct RtHolder {
 };
 thread_local RtHolder t_rt;
 std::atomic<int> g_rt_live(0);
+std::atomic<int> g_rt_peak(0);   // most threads that ever owned a runtime at the same time
 }  // namespace
 int live_runtimes() { return g_rt_live.load(); }
+int peak_runtimes() { return g_rt_peak.load(); }
+static size_t trim_idle_runtimes() {
+    std::lock_guard<std::mutex> lk(g_rt_mu);
+    size_t got = 0;
+    for (RtSlot* s : g_rt_free)
+        for (auto& kv : s->R.pool) {
+            DBuf& b = kv.second;
+            if (b.p && hipFree(b.p) == hipSuccess) got += b.cap;   // (the owning thread drained its streams before it left)
+            if (b.p) g_pool_bytes -= (long long)b.cap;
+            b.p = nullptr; b.cap = 0;
+        }
+    return got;
+}
 RtHolder::~RtHolder() { if (s) { std::lock_guard<std::mutex> lk(g_rt_mu); g_rt_free.push_back(s); g_rt_live--; } }
 
 int second_stream(Runtime* rt, hipStream_t* out) {
@@ -143,7 +170,7 @@ int runtime(Runtime** out) {
         std::lock_guard<std::mutex> lk(g_rt_mu);
         if (!g_rt_free.empty()) { t_rt.s = g_rt_free.back(); g_rt_free.pop_back(); }
         else t_rt.s = new RtSlot();
-        g_rt_live++;
+        { const int n = ++g_rt_live; int pk = g_rt_peak.load(); while (n > pk && !g_rt_peak.compare_exchange_weak(pk, n)) {} }
         if (t_rt.s->state == 1) (void)hipSetDevice(t_rt.s->R.device);   // the current device is per-thread state
     }
     Runtime& R = t_rt.s->R;
@@ -188,15 +215,52 @@ int runtime(Runtime** out) {
     return PS_OK;
 }
 
-void prof_begin(Runtime* rt) { if (rt->prof_on) (void)hipEventRecord(rt->ev0, rt->stream); }
+static hipEvent_t prof_event(Runtime* rt) {
+    hipEvent_t e = nullptr;
+    if (!rt->prof_spare.empty()) { e = rt->prof_spare.back(); rt->prof_spare.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+}
+void prof_begin(Runtime* rt) {
+    if (!rt->prof_on) return;
+    if (rt->prof_defer) {
+        Runtime::ProfPend p{prof_event(rt), nullptr, nullptr, 0.0};
+        if (p.a) (void)hipEventRecord(p.a, rt->stream);
+        rt->prof_pend.push_back(p);
+        return;
+    }
+    (void)hipEventRecord(rt->ev0, rt->stream);
+}
 void prof_end(Runtime* rt, const char* name, double bytes) {
     if (!rt->prof_on) return;
+    if (rt->prof_defer) {
+        if (rt->prof_pend.empty() || rt->prof_pend.back().b) return;
+        Runtime::ProfPend& p = rt->prof_pend.back();
+        p.b = prof_event(rt); p.name = name; p.bytes = bytes;   // (names are string literals)
+        if (p.b) (void)hipEventRecord(p.b, rt->stream);
+        return;
+    }
     (void)hipEventRecord(rt->ev1, rt->stream);
     (void)hipEventSynchronize(rt->ev1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, rt->ev0, rt->ev1);
     Prof& p = rt->prof[name];
     p.ms += ms; p.launches += 1; p.bytes += bytes;
+}
+// read the queued event pairs (deferred mode); the stream is drained first
+void prof_flush(Runtime* rt) {
+    if (rt->prof_pend.empty()) return;
+    (void)hipStreamSynchronize(rt->stream);
+    for (Runtime::ProfPend& q : rt->prof_pend) {
+        float ms = 0;
+        if (q.a && q.b && q.name && hipEventElapsedTime(&ms, q.a, q.b) == hipSuccess) {
+            Prof& p = rt->prof[q.name];
+            p.ms += ms; p.launches += 1; p.bytes += q.bytes;
+        }
+        if (q.a) rt->prof_spare.push_back(q.a);
+        if (q.b) rt->prof_spare.push_back(q.b);
+    }
+    rt->prof_pend.clear();
 }
 
 // ------------------------------------------------------------------------------------------ sequences
@@ -298,20 +362,22 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
     return PS_OK;
 }
 
-// this runtime's share of the device memory for DP matrices (rec + flg = 18 bytes per slot): PORESEQ_MAX_BATCH_GB when set (read
-// at every call), otherwise 65 % of the device divided by four — the pools of a runtime only grow, so the share must not depend on
-// how many host threads happen to drive the GPU at the moment (by more than four, if that many own a runtime).  288 GB -> 47 GB per
-// runtime: a lone region's 170 candidate alignments (24 GB) stay one launch; a lock-step batch of 16 regions takes ~170 workgroups
-// of two 10 kb sweeps per launch.
+// This runtime's share of the device memory for DP matrices (rec + flg = 18 bytes per slot): PORESEQ_MAX_BATCH_GB when set (read
+// at every call), otherwise 65 % of the device divided by the most threads that ever owned a runtime at once (at least four).
+// The count only goes up, so shares only go down: pools sized under a larger share are given back at the owner's next
+// Batch::place, and after the first step of a multi-threaded driver every pool fits its share for good (no regrowth, no thrash).
+// 288 GB -> 47 GB per runtime up to four threads: a lone region's 170 candidate alignments (24 GB) stay one launch; a lock-step
+// batch of 16 regions takes ~170 workgroups of two 10 kb sweeps per launch.  Callers size their batches on a guess of the band
+// footprint (guess_slots) and split when realign() finds the matrices 20 % over the share, or the device short of memory.
 double device_share_bytes() {
     if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 48e9;
-    return std::max(2e9, 0.65 * (double)tot / std::max(4, live_runtimes()));
+    return std::max(2e9, 0.65 * (double)tot / std::max(4, peak_runtimes()));
 }
 
 // second phase: the anti-diagonal footprint of every band is known, size the skewed matrices
-int Batch::place(Runtime* rt, int P_) {
+int Batch::place(Runtime* rt, int P_, bool can_split) {
     P = std::min(Pmax, std::max(64, ((P_ + 63) / 64) * 64));
     if (const char* fp = getenv("PORESEQ_DEBUG_MIN_P")) P = std::min(Pmax, std::max(P, atoi(fp)));  // experiments only
     int64_t mat_tot = 0;
@@ -321,8 +387,29 @@ int Batch::place(Runtime* rt, int P_) {
         for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot + (int64_t)MAT_FRONT * P; mat_tot += (j.S + MAT_FRONT + MAT_BACK) * P; }
     }
     cells = mat_tot;
-    PS_TRY(rt->buf("rec").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(double2)));
-    PS_TRY(rt->buf("flg").ensure(std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short)));
+    {
+        // The matrices are the only big pools, and several runtimes size theirs at different times (the share depends on how many
+        // threads are inside the library).  Two rules keep the sum below the device: a runtime whose pools were sized for a much
+        // larger share than today's gives them back before re-sizing, and no matrix pool grows into the last 8 % of the device
+        // (small buffers of every runtime live there) — PS_ERR_NOMEM instead, which callers that can split turn into smaller batches.
+        DBuf& rec = rt->buf("rec");
+        DBuf& flg = rt->buf("flg");
+        const size_t need_rec = (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(double2), need_flg = (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short);
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
+        if (!getenv("PORESEQ_MAX_BATCH_GB") && rec.p && (double)rec.cap > 1.5 * device_share_bytes() + 2e9 && need_rec < rec.cap) {
+            PS_HIP(hipStreamSynchronize(rt->stream));
+            PS_HIP(hipFree(rec.p)); g_pool_bytes -= (long long)rec.cap; rec.p = nullptr; rec.cap = 0;
+            if (flg.p) { PS_HIP(hipFree(flg.p)); g_pool_bytes -= (long long)flg.cap; flg.p = nullptr; flg.cap = 0; }
+        }
+        if (tot && (need_rec > rec.cap || need_flg > flg.cap)) {
+            auto over = [&] { return (double)(g_pool_bytes.load() - (long long)rec.cap - (long long)flg.cap) + (double)need_rec + (double)need_flg > 0.92 * (double)tot; };
+            if (over()) (void)trim_idle_runtimes();
+            if (over() && can_split) return fail(PS_ERR_NOMEM, "the DP matrices of this batch do not fit beside the pools of the other threads' batches");
+        }
+        PS_TRY(rec.ensure(need_rec));
+        PS_TRY(flg.ensure(need_flg));
+    }
     PS_TRY(rt->up(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD)));
     d.rec = rt->buf("rec").as<double2>(); d.flg = rt->buf("flg").as<unsigned short>();
     return PS_OK;
@@ -476,7 +563,7 @@ int Align::refs_to_host(Runtime* rt) {
 
 // forward fill + backtrace + updaterefs of a batch (the body of ScoreAlignments per event,
 // cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
-int realign(Runtime* rt, Batch& b) {
+int realign(Runtime* rt, Batch& b, double cap) {
     if (!b.d.njobs) return PS_OK;
     PS_TRY(launch_begin(rt, b.d));
     PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
@@ -491,7 +578,25 @@ int realign(Runtime* rt, Batch& b) {
         return fail(PS_ERR_UNSUPPORTED, "band footprint of " + std::to_string(*w) + " rows on one anti-diagonal: wider than two slots per lane of one "
                                         "workgroup (2046); realign_width up to 1022 fits for any input");
     { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign: %d jobs x %d, widest footprint %d\n", b.d.njobs, b.ndir, *w); }
-    PS_TRY(b.place(rt, std::max(*w, 1) + 9 <= 1024 ? std::max(*w, 1) + 9 : ((std::max(*w, 1) + 2 + 127) / 128) * 128));
+    const int Pneed = std::max(*w, 1) + 9 <= 1024 ? std::max(*w, 1) + 9 : ((std::max(*w, 1) + 2 + 127) / 128) * 128;
+    if (cap > 0) {   // the caller sized this batch on a guess of the footprint: let it split when the real one is much wider
+        const int Pr = std::min(b.Pmax, std::max(64, ((Pneed + 63) / 64) * 64));
+        double bytes = 0;
+        for (const JobD& j : b.jobs) bytes += (double)(j.S + MAT_FRONT + MAT_BACK) * Pr * 18.0 * b.ndir;
+        if (bytes > cap) {
+            static const bool trace2 = getenv("PORESEQ_TRACE") != nullptr;
+            if (trace2) fprintf(stderr, "[ps] realign: %.1f GB of matrices at %d slots per anti-diagonal, over the share: split\n", bytes * 1e-9, Pr);
+            b.P = Pr;
+            return PS_SPLIT;
+        }
+    }
+    {
+        const int rc = b.place(rt, Pneed, cap > 0);
+        // several runtimes share the device and sized their pools at different times: when the matrices cannot be had even after the
+        // idle pools were taken back (DBuf::ensure), a caller that can split does so instead of failing
+        if (rc == PS_ERR_NOMEM && cap > 0) { b.P = std::min(b.Pmax, std::max(64, ((Pneed + 63) / 64) * 64)); return PS_SPLIT; }
+        PS_TRY(rc);
+    }
     if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs * b.ndir; }
     PS_TRY(launch_fill(rt, b.d, b.jobs, b.ndir, b.maxS, b.P, b.ncols));
     PS_TRY(launch_backtrace(rt, b.d, b.maxn));
@@ -511,6 +616,15 @@ void par_for(int n, const std::function<void(int)>& fn) {
     for (std::thread& x : th) x.join();
 }
 
+// Slots per anti-diagonal realign() will probably need for this AlignData: footprint ~ (2W + 1) / 1.9 for about one level per base, + 9.
+// Only a guess (ragged remapped alignments, few levels per base: up to 2W + 1): callers that size batches on it pass realign() a cap
+// and split when it answers PS_SPLIT.  PORESEQ_DEBUG_GUESS_P overrides it (tests: a wrong guess).
+int guess_slots(const Align* a) {
+    static const int dbg = getenv("PORESEQ_DEBUG_GUESS_P") ? atoi(getenv("PORESEQ_DEBUG_GUESS_P")) : 0;
+    const int g = dbg > 0 ? dbg : (((2 * a->par.realign_width + 1) * 10 / 19 + 9 + 63) / 64) * 64;
+    return std::min(1024, std::max(64, g));
+}
+
 // How many of the AlignData as[k0..] fit this runtime's device share when each event takes `ndir` sweeps (at least one)
 static size_t fit_share(const std::vector<Align*>& as, size_t k0, int ndir) {
     const double cap = device_share_bytes();
@@ -518,7 +632,7 @@ static size_t fit_share(const std::vector<Align*>& as, size_t k0, int ndir) {
     size_t k = k0;
     for (; k < as.size(); k++) {
         const Align* a = as[k];
-        const int P = std::min(1024, std::max(64, (((2 * a->par.realign_width + 1) * 10 / 19 + 9 + 63) / 64) * 64));
+        const int P = guess_slots(a);
         double add = 0;
         for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + a->states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0 * ndir;
         if (k > k0 && bytes + add > cap) break;
@@ -549,7 +663,17 @@ int score_alignments_multi(Runtime* rt, const std::vector<Align*>& as, const std
     if (specs.empty()) return PS_OK;
     Batch b;
     PS_TRY(b.build(rt, specs, 1, 0));
-    PS_TRY(realign(rt, b));
+    {
+        const int rc = realign(rt, b, as.size() > 1 ? 1.2 * device_share_bytes() : 0.0);
+        if (rc == PS_SPLIT) {   // bands wider than fit_share guessed: two halves, one after the other
+            const size_t h = as.size() / 2;
+            PS_TRY(score_alignments_multi(rt, std::vector<Align*>(as.begin(), as.begin() + h), std::vector<double*>(scores.begin(), scores.begin() + h),
+                                          std::vector<double*>(likes.begin(), likes.begin() + h)));
+            return score_alignments_multi(rt, std::vector<Align*>(as.begin() + h, as.end()), std::vector<double*>(scores.begin() + h, scores.end()),
+                                          std::vector<double*>(likes.begin() + h, likes.end()));
+        }
+        PS_TRY(rc);
+    }
     std::vector<JobOut*> outs(as.size(), nullptr);
     for (size_t k = 0; k < as.size(); k++) {
         as[k]->host_refs_valid = false;
@@ -728,7 +852,17 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     if (specs.empty()) return PS_OK;
     Batch b;
     PS_TRY(b.build(rt, specs, 2, extra));
-    PS_TRY(realign(rt, b));
+    {
+        const int rc = realign(rt, b, R > 1 ? 1.2 * device_share_bytes() : 0.0);
+        if (rc == PS_SPLIT) {   // bands wider than fit_share guessed: two halves, one after the other
+            const size_t h = as.size() / 2;
+            PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin(), as.begin() + h), std::vector<const std::vector<Mut>*>(muts.begin(), muts.begin() + h),
+                                         std::vector<std::vector<Mut>*>(outs.begin(), outs.begin() + h)));
+            return score_mutations_multi(rt, std::vector<Align*>(as.begin() + h, as.end()), std::vector<const std::vector<Mut>*>(muts.begin() + h, muts.end()),
+                                         std::vector<std::vector<Mut>*>(outs.begin() + h, outs.end()));
+        }
+        PS_TRY(rc);
+    }
     for (Align* a : as) a->host_refs_valid = false;
     tk.lap("realign enqueue");
     par_for(R, [&](int k) { plan_tables(as[k], *muts[k], &plan[k], R == 1 ? 8 : (R <= 4 ? 4 : 1)); });

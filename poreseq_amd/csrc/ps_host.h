@@ -42,7 +42,7 @@ struct Batch {
     int ndir = 1, P = 0, Pmax = 64, maxC = 0, maxn = 0, maxlbn = 0;
     int64_t maxS = 0, cells = 0, ncols = 0;
     int build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir, int lb_extra);
-    int place(Runtime* rt, int P);
+    int place(Runtime* rt, int P, bool can_split = false);
     double fill_alg_bytes() const;
 };
 
@@ -82,7 +82,8 @@ std::vector<int> states_of(const std::string& bases);
 std::string apply_edit(const std::string& b, const Mut& m);
 void accumulate_likes(const double* ra, const double* rl, int n, int C, double* likes);
 
-int realign(Runtime* rt, Batch& b);
+constexpr int PS_SPLIT = 1;   // realign(): the matrices would exceed `cap` bytes; nothing was launched, b.P holds the width they need
+int realign(Runtime* rt, Batch& b, double cap = 0.0);
 int score_alignments(Runtime* rt, Align* a, double* scores, double* likes);
 // the *_multi forms run the same call for several AlignData (independent regions) in one launch chain
 void par_for(int n, const std::function<void(int)>& fn);
@@ -91,7 +92,9 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
                          const std::vector<std::vector<Mut>*>& outs);
 int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<RandState*>& rngs, int nkeep, double skip, double stay,
                          double mmin, double mmax, const std::vector<std::vector<std::string>*>& outs);
+int peak_runtimes();   // most host threads that ever owned a runtime at the same time
 int live_runtimes();   // host threads that currently own a runtime
+int guess_slots(const Align* a);   // anti-diagonal footprint realign() will probably choose
 double device_share_bytes();   // this runtime's share of the device memory for DP matrices
 int make_mutations_multi(Runtime* rt, const std::vector<Align*>& as, std::vector<std::vector<Mut>> muts, std::vector<int>* nbases);
 int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,

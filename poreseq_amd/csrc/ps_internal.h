@@ -85,6 +85,12 @@ struct Runtime {
     HBuf& hbuf(const std::string& name) { return hpool[name]; }
     std::map<std::string, Prof> prof;
     bool prof_on = false;
+    // prof_defer: event pairs are queued and read when the profile is asked for (ps_prof_get) instead of after every launch, so
+    // that profiling does not serialise the host with the stream (bench.py profiles inside its timed region this way)
+    bool prof_defer = false;
+    struct ProfPend { hipEvent_t a, b; const char* name; double bytes; };
+    std::vector<ProfPend> prof_pend;
+    std::vector<hipEvent_t> prof_spare;
     DBuf& buf(const std::string& name) { return pool[name]; }
     Stage stage;
     // enqueue host -> device through the arena (the source may die as soon as this returns)
@@ -213,6 +219,7 @@ struct VitRegionH {
 int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, int nkeep, double skip, double stay, double mmin, double mmax,
                          std::vector<std::vector<std::vector<int>>>* paths);
 
+void prof_flush(Runtime* rt);   // deferred mode: read the queued event pairs (drains the stream)
 void prof_begin(Runtime* rt);
 void prof_end(Runtime* rt, const char* name, double alg_bytes);
 

@@ -89,3 +89,35 @@ def test_hip_batch_score_events_and_memory_chunking(monkeypatch):
     with RegionBatch(pas) as rb:
         got = rb.ScoreEvents()
     assert got == [B.make_pa(PSAlign, d, copy.deepcopy(ev), P).ScoreEvents() for d, ev, _ in regs]
+
+
+@pytest.mark.gpu
+def test_hip_seed_chunks_are_cut_again_when_the_bands_are_wider_than_guessed():
+    """FindMutations sizes its candidate batches on a guess of the band footprint; with a guess far too small
+    (PORESEQ_DEBUG_GUESS_P) the first chunk must be re-cut, and the results stay the same"""
+    import hashlib, json, os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import hashlib, json, sys\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from test_batch import _regions, _lock_step, P\n"
+        "from poreseq_amd.poreseqcpp import PSAlign, swalign\n"
+        "regs = _regions([(900, 8), (700, 6)], 7500, swalign)\n"
+        "res, logs = _lock_step(PSAlign, regs, P)\n"
+        "h = hashlib.sha1(json.dumps(logs, default=str).encode())\n"
+        "for s, a, ras, rls in res:\n"
+        "    h.update(str(s).encode()); h.update(repr(a).encode())\n"
+        "    for u in ras + rls: h.update(u.tobytes())\n"
+        "print('DIGEST', h.hexdigest())\n"
+    ) % (os.path.dirname(here), here)
+    def run(extra):
+        env = dict(os.environ, PORESEQ_TRACE="1", **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0], r.stderr
+    want, err0 = run({})
+    got, err1 = run({"PORESEQ_DEBUG_GUESS_P": "64", "PORESEQ_MAX_BATCH_GB": "0.2"})
+    assert "cut again" not in err0 and "over the share" not in err0
+    assert "cut again" in err1           # FindMutations' candidate batches
+    assert "over the share" in err1      # the lock-step realigns of ScoreAlignments / ScoreMutations
+    assert got == want
