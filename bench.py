@@ -279,7 +279,7 @@ def main():
                     tj = json.load(fh)
                 tk = tj["kernels"].get(KERNEL_OF[dom])
                 same = (tk and tj.get("length") == args.length and tj.get("events") == args.events and tj.get("regions_per_batch") == max(1, R // NB)
-                        and abs(tk["alg_bytes_per_launch"] / roof["alg_bytes_per_launch"] - 1.0) < 0.05)
+                        and abs(tk["alg_bytes_per_launch"] / roof["alg_bytes_per_launch"] - 1.0) < 0.10)
                 if same:
                     roof["traffic"] = tk["fetch_bytes_per_launch"] + tk["write_bytes_per_launch"]
                     roof["traffic_source"] = "profiles/r02_traffic.json: " + tj.get("source", "")
