@@ -336,7 +336,6 @@ __device__ __forceinline__ double fill_emission(const FillCtx& c, const double (
 //    at most half of a CU's 160 KB of LDS, so two workgroups share a CU.
 template <bool CMP>
 __device__ __forceinline__ void fill_model_row(const FillCtx& c, int state, double (&m)[8]) {
-    static_assert(MODEL_ROW_BYTES == 80, "row address below is state * 64 + state * 16");
     const int st0 = state < 0 ? 0 : state;
     double2 a, bq, cq, dq;
     if (CMP) {
@@ -344,7 +343,7 @@ __device__ __forceinline__ void fill_model_row(const FillCtx& c, int state, doub
         a = *(const double2*)(c.mdl + q0); bq = *(const double2*)(c.mdl + (q0 ^ 16u));
         cq = *(const double2*)(c.mdl + (q0 ^ 32u)); dq = *(const double2*)(c.mdl + (q0 ^ 48u));
     } else {
-        const char* row = c.mdl + ((st0 << 6) + (st0 << 4));
+        const char* row = c.mdl + __umul24((unsigned)st0, (unsigned)MODEL_ROW_BYTES);   // v_mul_u32_u24: full rate (the compiler's v_mul_lo_u32 for (s << 6) + (s << 4) is not)
         a = *(const double2*)row; bq = *(const double2*)(row + 16); cq = *(const double2*)(row + 32); dq = *(const double2*)(row + 48);
     }
     m[0] = a.x; m[1] = a.y; m[2] = bq.x; m[3] = bq.y; m[4] = cq.x; m[5] = cq.y; m[6] = dq.x; m[7] = dq.y;
