@@ -379,7 +379,7 @@ double device_share_bytes() {
 // second phase: the anti-diagonal footprint of every band is known, size the skewed matrices
 int Batch::place(Runtime* rt, int P_, bool can_split) {
     P = std::min(Pmax, std::max(64, ((P_ + 63) / 64) * 64));
-    if (const char* fp = getenv("PORESEQ_DEBUG_MIN_P")) P = std::min(Pmax, std::max(P, atoi(fp)));  // experiments only
+    if (const char* fp = getenv("PORESEQ_DEBUG_MIN_P")) P = std::min(1024, std::max(P, (atoi(fp) + 63) / 64 * 64));  // tests / experiments: more slots than needed
     int64_t mat_tot = 0;
     for (JobD& j : jobs) {
         j.P = P;

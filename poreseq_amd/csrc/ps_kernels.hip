@@ -1375,7 +1375,8 @@ int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int
     // forward-only jobs of one event (candidate sequences of FindMutations), longest with longest
     // (a launch that fits the chip with one sweep per workgroup keeps them apart: a lone sweep finishes ~20 % sooner than a pair,
     //  and a launch this small is on some region's critical path)
-    static const int pair_min = getenv("PORESEQ_DEBUG_PAIR_MIN") ? atoi(getenv("PORESEQ_DEBUG_PAIR_MIN")) : PAIR_MIN_SWEEPS;   // (tuning probes)
+    const char* pm_env = getenv("PORESEQ_DEBUG_PAIR_MIN");   // (tests and tuning probes: read at every launch)
+    const int pair_min = pm_env ? atoi(pm_env) : PAIR_MIN_SWEEPS;
     bool pair = 2 * P <= 768 && b.njobs * ndir > pair_min;
     std::vector<int> pr;
     if (pair && ndir == 2) {

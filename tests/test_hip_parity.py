@@ -269,10 +269,17 @@ def test_tiny_sequences_match_oracle():
         assert np.array_equal(scores(mk(PSAlign).ScorePoints()), scores(mk(B.OraclePSAlign).ScorePoints())), L
 
 
-def test_bands_that_jump_and_resume_match_oracle():
+@pytest.mark.parametrize("layout", ["auto", "pairs", "plain", "plain-pairs"])
+def test_bands_that_jump_and_resume_match_oracle(layout, monkeypatch):
     """Narrow bands on events whose ref_align jumps (levels cut out, alignments shifted): the band leaves empty anti-diagonals
     behind and resumes further down — k_fill's SLOW bodies in the middle of a sweep, rows jumping by more than P — against the oracle,
-    matrices included."""
+    matrices included.  Every build of k_fill sees them: what the launcher picks for sweeps this small (lone, compact LDS layout,
+    slow bodies derived from the streamed band ends), two sweeps per workgroup, and the plain layout (LDS bitmap of slow bodies) that
+    sweeps of more than 256 lanes take, alone and in pairs."""
+    if "pairs" in layout:
+        monkeypatch.setenv("PORESEQ_DEBUG_PAIR_MIN", "0")
+    if "plain" in layout:
+        monkeypatch.setenv("PORESEQ_DEBUG_MIN_P", "320")
     rng = np.random.default_rng(5)
     for W, seed in ((3, 1), (5, 2), (8, 3), (17, 4)):
         Pn = dict(P0, realign_width=float(W), scoring_width=4.0, point_width=3.0)
