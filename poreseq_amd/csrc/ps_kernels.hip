@@ -1128,8 +1128,10 @@ __global__ __launch_bounds__(256) void k_oldfin(BatchD b, ScoreArgs a) {
 // scoreMutation (cpp/Alignment.cpp:447-512): G lanes per (event, edit) item, lane = new column,
 // rows stream through the group systolically (lane c works on row  base + t - c  at step t).
 // ------------------------------------------------------------------------------------------------
+// (at most 96 VGPRs — five waves per SIMD: with 100 a workgroup's wave did not fit beside the two 208-register waves a lone k_fill
+//  sweep keeps on SIMD 0 and 1, so k_score ran only on CUs without a fill: 1.07 ms per launch in the bench against 0.25 ms alone)
 template <int G, bool FD>
-__global__ __launch_bounds__(256) void k_score(BatchD b, ScoreArgs a, const int* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_score(BatchD b, ScoreArgs a, const int* __restrict__ items, int nitems) {
     constexpr int IPW = 64 / G;
     __shared__ double s_carry[(G == 64) ? 4 * 1024 : 1];   // last column of a 64-column chunk, per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
