@@ -7,7 +7,7 @@ poreseq/Mutate.py:70-85) over one BATCH of R independent synthetic regions, each
 parallelism (one process per region file, README.md:48-54).  One GPU refines the R regions of a step as B lock-step
 batches (poreseq_amd.batch / the ps_batch_* entry points; one host thread and one stream per batch): every phase of the
 schedule is one launch chain over all of a batch's events, with the default HIP environment (no extra hardware queues,
-no per-region threads or streams).  Default: 96 regions as 6 batches of 16.
+no per-region threads or streams).  Default: 140 regions as 7 batches of 20.
 The events of a step's regions are resident in HBM when the clock starts (RegionBatch.load: the marshalling + H2D copy
 a PSAlign call would do); DESIGN.md section 7 gives the PCIe-inclusive rate.  With N GPUs every rank refines its own
 batch per step (weak scaling, no data-path collective) and the value is the whole-job rate
@@ -96,8 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--events", type=int, default=10)
-    ap.add_argument("--regions-per-gpu", type=int, default=96, help="independent regions refined on one GPU per step")
-    ap.add_argument("--batches-in-flight", type=int, default=6,
+    ap.add_argument("--regions-per-gpu", type=int, default=140, help="independent regions refined on one GPU per step")
+    ap.add_argument("--batches-in-flight", type=int, default=7,
                     help="lock-step batches per GPU (one host thread each): while one batch is in a thin phase or on the host, "
                          "the others keep the GPU full; the regions of a step are dealt round-robin to the batches")
     ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")

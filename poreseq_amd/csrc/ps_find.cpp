@@ -138,8 +138,28 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
         for (const std::string& s : *seeds[r]) pairs.push_back({&as[r]->bases, &s});
     }
     pair0[R] = (int)pairs.size();
+    // The batch's checkpoint rows / columns (~13 MB per 10 kb pair) are a pool like the DP matrices: at most an eighth of this
+    // runtime's share goes into one launch.  The first chunk overlaps with the base realign; what is left (large lock-step batches
+    // only) follows it, chunk by chunk, and a chunk the device has no memory for is cut in two.
+    auto sw_bytes = [&](size_t k) {
+        const double n1 = (double)pairs[k].first->size(), n2 = (double)pairs[k].second->size();
+        return 4.0 * ((n1 / 64 + 1) * (n2 + 8) + (n2 / 64 + 1) * (n1 + 1)) + 8.0 * (n1 + n2 + 2);
+    };
+    double sw_cap = device_share_bytes() / 8;
+    auto sw_chunk_end = [&](size_t k0) {
+        double acc = 0;
+        size_t k = k0;
+        for (; k < pairs.size(); k++) { const double add = sw_bytes(k); if (k > k0 && acc + add > sw_cap) break; acc += add; }
+        return k;
+    };
+    typedef std::vector<std::pair<const std::string*, const std::string*>> SwIn;
     SwJob swjob;
-    PS_TRY(sw_launch(rt, pairs, &swjob));
+    size_t sw_first = sw_chunk_end(0);
+    {
+        const int rc = sw_launch(rt, SwIn(pairs.begin(), pairs.begin() + sw_first), &swjob);
+        if (rc == PS_ERR_NOMEM && sw_first > 1) { sw_first = 0; swjob = SwJob(); }   // nothing enqueued: everything goes the chunked way below
+        else PS_TRY(rc);
+    }
     tk.lap("sw enqueue");
     // re-align to the current sequences, keeping per-base cumulative likelihoods (cpp/FindMutations.cpp:28-29)
     std::vector<std::vector<double>> base(R), sc(R);
@@ -154,6 +174,16 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
     std::vector<SwResult> als_all;
     PS_TRY(sw_finish(rt, &swjob, &als_all));   // always drain the second stream, even on failure above
     PS_TRY(rc_base);
+    for (size_t k0 = sw_first; k0 < pairs.size();) {
+        const size_t k1 = sw_chunk_end(k0);
+        std::vector<SwResult> part;
+        const int rc = sw_batch(rt, SwIn(pairs.begin() + k0, pairs.begin() + k1), &part);
+        if (rc == PS_ERR_NOMEM && k1 - k0 > 1) { sw_cap *= 0.5; continue; }
+        PS_TRY(rc);
+        for (SwResult& r : part) als_all.push_back(std::move(r));
+        k0 = k1;
+    }
+    if (sw_first < pairs.size()) { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] smith-waterman: %zu pairs, %zu with the realign, the rest in chunks\n", pairs.size(), sw_first); }
     if (pairs.empty()) return PS_OK;
     par_for((int)als_all.size(), [&](int k) { fillinds(als_all[k]); });
     tk.lap("smith-waterman");

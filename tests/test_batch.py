@@ -117,7 +117,10 @@ def test_hip_seed_chunks_are_cut_again_when_the_bands_are_wider_than_guessed():
         return [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0], r.stderr
     want, err0 = run({})
     got, err1 = run({"PORESEQ_DEBUG_GUESS_P": "64", "PORESEQ_MAX_BATCH_GB": "0.2"})
-    assert "cut again" not in err0 and "over the share" not in err0
+    assert "cut again" not in err0 and "over the share" not in err0 and "the rest in chunks" not in err0
     assert "cut again" in err1           # FindMutations' candidate batches
     assert "over the share" in err1      # the lock-step realigns of ScoreAlignments / ScoreMutations
     assert got == want
+    got2, err2 = run({"PORESEQ_MAX_BATCH_GB": "0.002"})
+    assert "the rest in chunks" in err2  # Smith-Waterman batches larger than an eighth of the share
+    assert got2 == want
