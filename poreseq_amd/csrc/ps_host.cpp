@@ -135,10 +135,16 @@ struct RtHolder {
 };
 thread_local RtHolder t_rt;
 std::atomic<int> g_rt_live(0);
-std::atomic<int> g_rt_peak(0);   // most threads that ever owned a runtime at the same time
+std::atomic<int> g_rt_peak(0);   // most threads that owned a runtime at the same time (forgotten a minute after the count was last that high)
+std::atomic<double> g_rt_peak_at(0.0);
 }  // namespace
 int live_runtimes() { return g_rt_live.load(); }
-int peak_runtimes() { return g_rt_peak.load(); }
+int peak_runtimes() {
+    // a burst of threads long ago must not shrink a later lone caller's share for good
+    const double t = now_s();
+    if (t - g_rt_peak_at.load() > 60.0) { g_rt_peak.store(std::max(g_rt_live.load(), 1)); g_rt_peak_at.store(t); }
+    return g_rt_peak.load();
+}
 static size_t trim_idle_runtimes() {
     std::lock_guard<std::mutex> lk(g_rt_mu);
     size_t got = 0;
@@ -170,7 +176,12 @@ int runtime(Runtime** out) {
         std::lock_guard<std::mutex> lk(g_rt_mu);
         if (!g_rt_free.empty()) { t_rt.s = g_rt_free.back(); g_rt_free.pop_back(); }
         else t_rt.s = new RtSlot();
-        { const int n = ++g_rt_live; int pk = g_rt_peak.load(); while (n > pk && !g_rt_peak.compare_exchange_weak(pk, n)) {} }
+        {
+            const int n = ++g_rt_live;
+            int pk = g_rt_peak.load();
+            while (n > pk && !g_rt_peak.compare_exchange_weak(pk, n)) {}
+            if (n >= g_rt_peak.load()) g_rt_peak_at.store(now_s());
+        }
         if (t_rt.s->state == 1) (void)hipSetDevice(t_rt.s->R.device);   // the current device is per-thread state
     }
     Runtime& R = t_rt.s->R;
@@ -363,9 +374,10 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
 }
 
 // This runtime's share of the device memory for DP matrices (rec + flg = 18 bytes per slot): PORESEQ_MAX_BATCH_GB when set (read
-// at every call), otherwise 65 % of the device divided by the most threads that ever owned a runtime at once (at least four).
-// The count only goes up, so shares only go down: pools sized under a larger share are given back at the owner's next
-// Batch::place, and after the first step of a multi-threaded driver every pool fits its share for good (no regrowth, no thrash).
+// at every call), otherwise 65 % of the device divided by the most threads that owned a runtime at once (at least four; the maximum is
+// forgotten a minute after the count was last that high).  Within a run of a multi-threaded driver the count only goes up, so
+// shares only go down: pools sized under a larger share are given back at the owner's next Batch::place, and after the first
+// step every pool fits its share (no regrowth, no thrash).
 // 288 GB -> 47 GB per runtime up to four threads: a lone region's 170 candidate alignments (24 GB) stay one launch; a lock-step
 // batch of 16 regions takes ~170 workgroups of two 10 kb sweeps per launch.  Callers size their batches on a guess of the band
 // footprint (guess_slots) and split when realign() finds the matrices 20 % over the share, or the device short of memory.
