@@ -107,8 +107,9 @@ __device__ __forceinline__ unsigned sw_row(int (&G)[K], const int (&c2)[K], cons
 // ---- fill: grid (super-strips, pairs), block 64 * SWW ------------------------------------------------------------------
 // The workgroups of one pair's super-strips run concurrently, as one more level of the row pipeline: the last wave
 // of strip ss stores its boundary column (colsave) and, every 64 rows, publishes the row count with an agent-scope
-// release; the first wave of strip ss+1 acquires it before it reads those rows.  Workgroups are dispatched in
-// blockIdx order (strip index fastest), so a waiting strip's producer is always resident or finished.
+// release; the first wave of strip ss+1 acquires it before it reads those rows.  A workgroup takes its strip index from a
+// per-pair ticket (not from blockIdx, whose dispatch order HIP does not promise): whoever waits for strip ss-1 knows that a
+// workgroup holding that ticket started before it, so the producer is always resident or finished.
 constexpr int SW_SPIN_LIMIT = 1 << 22;
 template <int K>
 __global__ __launch_bounds__(64 * SWW) void k_sw_fill(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
