@@ -379,3 +379,26 @@ def test_large_properties_config2_shape():
     assert (sc[:3] > 20).all() and sc[3] < 0
     nb = pb.Refine()
     assert nb >= 3 and draft[300:-300] in pb.sequence      # the planted errors are repaired (ends may legitimately move)
+
+
+def test_profile_modes_count_the_same_launches():
+    """ps_prof_enable(1) (event pair read after every launch) and (2) (pairs queued, read by ps_prof_get: what bench.py uses
+    inside its timed steps) see the same launches, algorithmic bytes and work units; both measure a positive time"""
+    draft, events, truth = synth.make_region(500, 6, 31, B.oracle_swalign, P0)
+    api = _capi.load_hip()
+    rng = np.random.default_rng(3)
+    muts = synth.random_point_mutations(rng, draft, 40)
+    seen = {}
+    for mode in (1, 2):
+        h = api.align_create(draft, copy.deepcopy(events), P0)
+        hm = api.muts_create(muts)
+        api.prof_reset(); api.prof_enable(mode)
+        want = api.score_alignments(h, len(events))
+        api.muts_destroy(api.score_mutations(h, hm))
+        ms, n, nbytes = api.prof_get("fill")
+        ms2, n2, _ = api.prof_get("score")
+        seen[mode] = (n, nbytes, api.prof_units("fill"), n2, api.prof_units("score"), list(want))
+        api.prof_enable(0)
+        assert ms > 0 and ms2 > 0 and n >= 2 and n2 >= 1
+        api.muts_destroy(hm); api.align_destroy(h)
+    assert seen[1] == seen[2]
