@@ -267,11 +267,24 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": int(launches),
                     "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": nbytes / max(launches, 1),
                     "sweeps_per_launch": units / max(launches, 1) if dom == "fill" else None,
-                    "measured": "HIP events per launch inside the %d timed step(s), %d launches in flight side by side (one stream per "
-                                "lock-step batch): a launch's duration includes what it shares the chip with" % (args.steps, NB),
+                    "measured": "HIP events per launch inside the %d timed step(s), %d lock-step batches in flight (one stream each): a "
+                                "launch's duration includes what it shares the chip with" % (args.steps, NB),
                     "all_kernel_classes_ms_per_step": {c: v[0] / max(args.steps, 1) for c, v in tot.items()}}
             # aggregate rate of the class over the wall time of the steps (launches of different batches overlap)
             roof["aggregate_alg_gbs"] = (nbytes / 1e9) / dt if dt > 0 else None
+            roof["launches_in_flight_mean"] = (ms / 1e3) / dt if dt > 0 else None
+            if not args.no_extras:
+                # the same kernel class with the chip to itself: one lock-step batch of the timed size, alone, event pair read after
+                # every launch (the kernel's own quality; the figures above include what a launch shares the chip with)
+                api.prof_reset()
+                api.prof_enable(1)
+                run_batch(regions[-1][:max(1, R // NB)])
+                api.prof_enable(0)
+                ims, il, ib = api.prof_get(dom)
+                if ims > 0:
+                    roof["one_batch_alone"] = {"avg_launch_ms": ims / max(il, 1), "alg_bytes_per_launch": ib / max(il, 1),
+                                               "achieved": (ib / 1e9) / (ims / 1e3), "frac": (ib / 1e9) / (ims / 1e3) / HBM_PEAK_GBS,
+                                               "launches": int(il)}
             # HBM-side bytes per launch cannot be collected from inside this process: rocprofv3 --pmc on this very command
             # (tools/pmc_bench.sh) writes profiles/r02_traffic.json; it is used only if its launch shape matches the live pass
             try:

@@ -204,8 +204,21 @@ int runtime(Runtime** out) {
             // overlap with the base realign inside FindMutations) is created on first use (second_stream()).
             // Partitioning the CUs between them (hipExtStreamCreateWithCUMask) was measured and made no
             // difference, so it is not used.
+            // The runtimes' streams are dealt round-robin to the device's stream priority levels (three on MI355X).  Not for the
+            // priorities' sake: HIP keeps a separate set of hardware queues per level (four each by default), and streams that share
+            // a hardware queue run their kernels one after the other.  Seven lock-step batches on one level = seven streams on four
+            // queues, three kernels in flight on average and 108 kb/s; over three levels every stream has a queue of its own: 121 kb/s.
+            // (PORESEQ_ONE_PRIORITY=1: all streams on the default level.)
+            auto make_stream = [&](hipStream_t* st) {
+                static std::atomic<int> seq(0);
+                static const bool one = getenv("PORESEQ_ONE_PRIORITY") != nullptr;
+                int lo = 0, hi = 0;
+                if (!one && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo > hi)
+                    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi + seq++ % (lo - hi + 1));
+                return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            };
             if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-                hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess ||
+                make_stream(&R.stream) != hipSuccess ||
                 hipEventCreate(&R.ev0) != hipSuccess || hipEventCreate(&R.ev1) != hipSuccess ||
                 hipEventCreate(&R.sw0) != hipSuccess || hipEventCreate(&R.sw1) != hipSuccess) {
                 state = -1; why = "HIP device initialisation failed";
