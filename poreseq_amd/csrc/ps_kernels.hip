@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "ps_internal.h"
+#include "ps_slowmask.h"
 
 namespace ps {
 
@@ -231,21 +232,7 @@ __device__ __forceinline__ unsigned long long resume_bits(int lov, int before) {
     const int prev = __builtin_amdgcn_update_dpp(before, lov, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
     return __ballot(lov >= 0 && prev < 0);
 }
-// Which 8-step bodies must run k_fill's SLOW variant because of the resumes `rm` of one chunk: a resume on anti-diagonal t makes
-// every body holding a step of [t - 6, t + 6] slow, i.e. a body starting at s0 is slow for a resume in [s0 - 6, s0 + 13].
-// bit 7: the last body of the chunk before, bits 8-15: the chunk's own bodies, bit 16: the first body of the chunk after
-__device__ __forceinline__ unsigned resume_spread(unsigned long long rm) {
-    if (!rm) return 0u;
-    unsigned r = (rm & 0x3Full) ? 0x80u : 0u;
-    r |= (rm >> 58) ? 0x10000u : 0u;
-#pragma unroll
-    for (int bd = 0; bd < 8; bd++) {
-        const int a = 8 * bd - 6;
-        const unsigned long long w = a < 0 ? (0xFFFFFull >> -a) : (0xFFFFFull << a);
-        r |= (rm & w) ? (0x100u << bd) : 0u;
-    }
-    return r;
-}
+// resume_spread(): which 8-step bodies the resumes of one chunk make SLOW (ps_slowmask.h, host-tested)
 
 constexpr int FB = 8;            // anti-diagonals per loop body
 constexpr int FCH = 64;          // anti-diagonals per chunk: lo / hi prefetch unit, flush interval of the column maxima
