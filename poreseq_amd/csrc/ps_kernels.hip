@@ -769,11 +769,13 @@ __device__ __forceinline__ void fill_idle(const int Smax) {
     __syncthreads();
 }
 
-// One workgroup = up to two sweeps (halves of P lanes each) over the SAME event, so that one 64 KB model table in LDS serves
+// One workgroup = up to two sweeps (halves of P lanes each) over the SAME event, so that one model table in LDS (80 KB) serves
 // both: the forward and backward fill of an alignment, or two candidate sequences against one event.  With P = 320 / 384 that is
 // 10 / 12 waves = 3 per SIMD: the four SIMDs carry equal instruction streams and one wave's exchange / barrier latency is covered
 // by the other two (a lone sweep's 5-6 waves leave one SIMD with two waves and the others waiting for it).
-// pairs[2 * blockIdx.x + h] = job * ndir + dir of half h, or -1.  PAIR = false: one sweep per workgroup (P > 384).
+// pairs[2 * blockIdx.x + h] = job * ndir + dir of half h, or -1.  PAIR = false: one sweep per workgroup (P > 384, launches of at
+// most PAIR_MIN_SWEEPS sweeps, forward sweeps whose events all differ).  CMP: the compact LDS layout of fill_model_row, lone sweeps
+// of up to 256 lanes (two workgroups per CU).
 // FASTDIV: tabulated reciprocals (the normal case) or IEEE divisions (some divisor of the AlignData is not a sane number)
 template <int MAXT, bool PAIR, bool FASTDIV, bool CMP>
 __global__ __launch_bounds__(MAXT) void k_fill(BatchD b, const int* __restrict__ pairs, int ndir, int P, int rcols, int slowwords, int halfbytes) {
