@@ -227,3 +227,32 @@ def test_oracle_matches_live_reference_random_sweep(seed):
         log.append(pv.Mutate(seqs="viterbi", reps=1)); log.append(pv.sequence)
         logs.append(log)
     assert logs[0] == logs[1]
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43, 44])
+def test_oracle_is_defined_on_alignments_with_holes_and_jumps(seed):
+    """The GPU tests hold the HIP path to the oracle on events whose ref_align has holes, jumps or nothing at all — inputs on
+    which the reference's own ViterbiMutate reads out of bounds.  The restatement must be well defined there: same answer twice,
+    and clean under tools/oracle_asan.sh (this test is part of that run)."""
+    rng = np.random.default_rng(seed)
+    P = dict(DEFAULT_PARAMS, verbose=0, realign_width=float(rng.choice([3, 8, 40])), scoring_width=float(rng.choice([4, 20])), point_width=3.0)
+    draft, events, truth = synth.make_region(int(rng.integers(120, 300)), 4, 700 + seed, B.oracle_swalign, P)
+    ev = copy.deepcopy(events)
+    for k, e in enumerate(ev):
+        n = e.ref_align.size
+        a, b = sorted(rng.integers(5, n - 5, 2))
+        e.ref_align[a:b] = 0
+        c = int(rng.integers(10, n - 50))
+        e.ref_align[c:c + 30] = np.minimum(e.ref_align[c:c + 30] + 40, len(draft) - 5) * (e.ref_align[c:c + 30] > 0)
+    ev[-1].ref_align[:] = 0
+    runs = []
+    for _ in range(2):
+        B.reset_rand()
+        pa = B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(ev), P)
+        log = [pa.ScoreEvents(), [s.score for s in pa.ScorePoints()]]
+        log.append(pa.Mutate(seqs="viterbi", reps=1)); log.append(pa.sequence)
+        log.append(pa.Mutate(reps=1)); log.append(pa.Refine()); log.append(pa.sequence)
+        log.append([e.ref_align.tolist() for e in pa.events])
+        runs.append(log)
+    assert runs[0] == runs[1]
+    assert runs[0][0][-1] == 0.0            # the unaligned event scores nothing

@@ -9,4 +9,4 @@ PORESEQ_ORACLE_SO=$PWD/oracle/libps_oracle_asan.so LD_PRELOAD=$ASAN ASAN_OPTIONS
   python -m pytest tests/test_oracle.py tests/test_golden_large.py tests/test_batch.py -x -q -m "not gpu" -k "not live_reference" "$@"
 # (test_oracle_matches_live_reference_full_api is left out: it loads the uninstrumented reference build into the same process, which
 #  dies under the ASan runtime before pytest can report; the oracle code it calls is covered by the other tests.)
-# Last run (round 2): 17 passed, no sanitizer report, 195 s.
+# Last run (round 2): 21 passed, no sanitizer report, 190 s.
