@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--batches-in-flight", type=int, default=7,
                     help="lock-step batches per GPU (one host thread each): while one batch is in a thin phase or on the host, "
                          "the others keep the GPU full; the regions of a step are dealt round-robin to the batches")
+    ap.add_argument("--scheduler", choices=["lock-step", "pool"], default="lock-step",
+                    help="lock-step: the regions of a step as B fixed batches (the measured default).  pool (experimental, "
+                         "poreseq_amd.pool): regions advance independently, B worker threads issue whichever native operation "
+                         "most regions wait for, for up to R/B regions at a time")
     ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip everything that touches the CPU checkers (oracle / reference)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-region, 1 kb and profiled passes (profiling runs)")
@@ -146,6 +150,19 @@ def main():
         every batch's events resident in HBM"""
         import threading
         nb = max(1, min(nb, len(regs)))
+        if args.scheduler == "pool" and nb > 1:
+            from poreseq_amd.pool import RegionPool
+            allpas = [as_pa(r) for r in regs]
+            pool = RegionPool(allpas).load()
+            if timed:
+                psdist.barrier()
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = pool.run(params, workers=nb, batch_size=max(1, len(regs) // nb))
+            if timed and torch.cuda.is_available():
+                torch.cuda.synchronize()
+            return time.perf_counter() - t0, res
         groups = [regs[k::nb] for k in range(nb)]
         pas = [[as_pa(r) for r in g] for g in groups]
         rbs = [RegionBatch(p) for p in pas]
@@ -246,6 +263,7 @@ def main():
                                "schedule per region; a step is %d independent regions per GPU, refined as %d lock-step batches "
                                "(events resident in HBM when the clock starts)" % (args.length // 1000, args.events, R, NB),
                    "region_bases": args.length, "events": args.events, "regions_per_gpu": R, "batches_in_flight": NB,
+                   "scheduler": args.scheduler,
                    "parallelism": "%d regions x %d GPU(s), %d host thread(s) per GPU, no data-path collective" % (R, world, NB)},
     }
 
@@ -321,7 +339,7 @@ def main():
                                                  [abs(x.score - y.score) / abs(y.score) for x, y in zip(gp, cp) if abs(y.score) > 1e-3])
             cpu = cpu_pre["cpu"]
             # the SAME size as the GPU workload: measured unit costs at this size, times the unit counts of the GPU's own schedule
-            if not args.no_extras:
+            if not args.no_extras and sched:
                 import numpy as np
                 d, ev, tr = regions[-1][0]
                 pa = B.make_pa(cls, d, copy.deepcopy(ev), params)
