@@ -46,43 +46,74 @@ class RegionPool:
                 self.regions.append(r)
         return self
 
-    def run(self, params=None, reps=4, refseqs=None, logs=None, workers=4, batch_size=16, serialize_native=False):
-        return _run_pool(self, params, reps, refseqs, logs, workers, batch_size, serialize_native)
+    def run(self, params=None, reps=4, refseqs=None, logs=None, workers=4, batch_size=16, serialize_native=False, stats=None,
+            policy=None):
+        """`stats`, when a dict, receives {kind: [native calls, regions served]}; `policy`: policy_greedy (default) / policy_fill"""
+        return _run_pool(self, params, reps, refseqs, logs, workers, batch_size, serialize_native, stats, policy or policy_greedy)
 
 
-def consensus_pool(pas, params=None, reps=4, refseqs=None, logs=None, workers=4, batch_size=16, api=None, serialize_native=False):
+def consensus_pool(pas, params=None, reps=4, refseqs=None, logs=None, workers=4, batch_size=16, api=None, serialize_native=False,
+                   stats=None, policy=None):
     """The consensus schedule of `consensus_region` for the independent regions `pas`, scheduled operation by operation.
     Returns [(sequence, accuracy)] in the order of `pas`.  `logs`, when given, is a list of lists receiving
     (call, nbases, sequence) per region after every PSAlign-level call, as `consensus_regions` records them.
     `serialize_native`: let one worker at a time into the native library (the CPU oracle switches glibc's process-wide rand()
     state per region and is not re-entrant; the HIP library is: every host thread has its own runtime and every region its own
     generator)."""
-    return RegionPool(pas, api).load().run(params, reps, refseqs, logs, workers, batch_size, serialize_native)
+    return RegionPool(pas, api).load().run(params, reps, refseqs, logs, workers, batch_size, serialize_native, stats, policy)
 
 
-def _run_pool(pool, params, reps, refseqs, logs, workers, batch_size, serialize_native):
-    pas, api, native = pool.pas, pool.api, pool.native
-    pool.load()
-    regions, pool.regions = pool.regions, None
-    n = len(pas)
-    refseqs = [pa.sequence for pa in pas] if refseqs is None else list(refseqs)
-    out = [None] * n
-    live = set(r.i for r in regions)
-    for i in range(n):
-        if i not in live:
-            out[i] = (refseqs[i], 100)                      # fewer than 5 events: handed back as loaded
+def policy_greedy(by_kind, running, workers, batch_size):
+    """whatever most regions wait for, at once (keeps every worker busy; batches may be small)"""
+    kind = max(_KINDS, key=lambda k: len(by_kind[k]))
+    return (kind, by_kind[kind][:batch_size]) if by_kind[kind] else None
 
-    def note(r, call, nb):
-        if logs is not None:
-            logs[r.i].append((call, nb, r.pa.sequence))
 
-    def new_call(r, point_width=False):
+def policy_fill(by_kind, running, workers, batch_size):
+    """a full batch if there is one; a partial one only while fewer than half of the workers are busy (otherwise wait for the
+    operations in flight to bring more regions to the same point)"""
+    kind = max(_KINDS, key=lambda k: len(by_kind[k]))
+    if not by_kind[kind]:
+        return None
+    if len(by_kind[kind]) >= batch_size or running < max(1, workers // 2):
+        return kind, by_kind[kind][:batch_size]
+    return None
+
+
+class _Engine:
+    """The regions' programs and the native operations they ask for; drivers (the threaded one below, the virtual-time one of
+    tools/pool_sim.py) decide which regions go into which call."""
+
+    def __init__(self, pool, params, reps, refseqs, logs):
+        self.pool, self.params, self.logs = pool, params, logs
+        self.api, self.native = pool.api, pool.native
+        pas = pool.pas
+        pool.load()
+        self.regions, pool.regions = pool.regions, None
+        self.refseqs = [pa.sequence for pa in pas] if refseqs is None else list(refseqs)
+        self.out = [None] * len(pas)
+        live = set(r.i for r in self.regions)
+        for i in range(len(pas)):
+            if i not in live:
+                self.out[i] = (self.refseqs[i], 100)        # fewer than 5 events: handed back as loaded
+        for r in self.regions:
+            r.prog = self._program(r, reps)
+            r.result = None
+            self.advance(r)
+
+    # -- a region's program: the schedule of consensus_region, call by call ---------------------------------------------------
+    def _note(self, r, call, nb):
+        if self.logs is not None:
+            self.logs[r.i].append((call, nb, r.pa.sequence))
+
+    def _new_call(self, r, point_width=False):
         p = r.pa.params
         w = p['point_width'] if (point_width and 'point_width' in p) else p.get('scoring_width', 150)
-        api.check(api.lib.ps_align_new_call(r.h, int(w)))
+        self.api.check(self.api.lib.ps_align_new_call(r.h, int(w)))
 
-    def rounds(r, propose, nrounds):
+    def _rounds(self, r, propose, nrounds):
         """nrounds x {propose -> ScoreMutations -> MakeMutations}; ends when a round changes nothing (pyx:417-431)"""
+        api = self.api
         tot = 0
         for _ in range(nrounds):
             hm = yield from propose()
@@ -100,8 +131,9 @@ def _run_pool(pool, params, reps, refseqs, logs, workers, batch_size, serialize_
         r.pa.sequence = api.align_sequence(r.h)
         return tot
 
-    def mutate(r, kind, nrounds):
-        new_call(r)
+    def _mutate(self, r, kind, nrounds):
+        api = self.api
+        self._new_call(r)
         if kind == 'self':
             cand = [x.sequence for x in r.pa.events[::2]]
         else:
@@ -112,56 +144,78 @@ def _run_pool(pool, params, reps, refseqs, logs, workers, batch_size, serialize_
             hm = yield ("find", hseq)
             return hm
         try:
-            tot = yield from rounds(r, propose, nrounds)
+            tot = yield from self._rounds(r, propose, nrounds)
         finally:
             api.seqs_destroy(hseq)
         return tot
 
-    def refine(r):
-        new_call(r, point_width=True)
+    def _refine(self, r):
+        self._new_call(r, point_width=True)
 
         def propose():
-            return api.find_point_mutations(r.h)
+            return self.api.find_point_mutations(r.h)
             yield   # (a generator: FindPointMutations is host-only and needs no batching)
-        return (yield from rounds(r, propose, 1))
+        return (yield from self._rounds(r, propose, 1))
 
-    def program(r):
-        note(r, "Mutate:self", (yield from mutate(r, 'self', reps)))
+    def _program(self, r, reps):
+        self._note(r, "Mutate:self", (yield from self._mutate(r, 'self', reps)))
         for _ in range(reps):
-            note(r, "Mutate:viterbi", (yield from mutate(r, 'viterbi', 4)))
-            nb = yield from refine(r)
-            note(r, "Refine", nb)
+            self._note(r, "Mutate:viterbi", (yield from self._mutate(r, 'viterbi', 4)))
+            nb = yield from self._refine(r)
+            self._note(r, "Refine", nb)
             if nb == 0:
                 break
 
-    lock = threading.Condition()
-    native_lock = threading.Lock()
-    state = {"running": 0, "error": None}
-
-    def advance(r):
-        """run the region's program up to its next native operation (called with the lock NOT held: host-side work only)"""
+    # -- what a driver needs ------------------------------------------------------------------------------------------------
+    def advance(self, r):
+        """run the region's program up to its next native operation (host-side work only)"""
         try:
             r.want, r.arg = r.prog.send(r.result)
         except StopIteration:
             r.want, r.arg = None, None
         r.result = None
 
-    for r in regions:
-        r.prog = program(r)
-        r.result = None
-        advance(r)
-
-    def issue(kind, group):
+    def issue(self, kind, group):
+        """one batched native call for the regions `group`, all waiting for `kind`; then every program moves on"""
+        api = self.api
         hs = [r.h for r in group]
         if kind == "viterbi":
-            return api.batch_viterbi_mutate(hs, [r.rng for r in group], 16, 0.05, 0.01, 0.33, 0.75)
-        if kind == "find":
-            return api.batch_find_mutations(hs, [r.arg for r in group])
-        if kind == "score":
-            return api.batch_score_mutations(hs, [r.arg for r in group])
-        return api.batch_make_mutations(hs, [r.arg for r in group])
+            res = api.batch_viterbi_mutate(hs, [r.rng for r in group], 16, 0.05, 0.01, 0.33, 0.75)
+        elif kind == "find":
+            res = api.batch_find_mutations(hs, [r.arg for r in group])
+        elif kind == "score":
+            res = api.batch_score_mutations(hs, [r.arg for r in group])
+        else:
+            res = api.batch_make_mutations(hs, [r.arg for r in group])
+        for r, x in zip(group, res):
+            r.result = x
+            self.advance(r)
 
-    waiting = [r for r in regions if r.want is not None]
+    def finish(self, ok=True):
+        api = self.api
+        try:
+            if ok:
+                for r in self.regions:
+                    pa = r.pa
+                    pa.sequence = api.align_sequence(r.h)
+                    api.align_update_events(r.h, pa.events)
+                    p = pa.params if self.params is None else self.params
+                    if 'end_trim' in p and len(pa.sequence) > 2 * p['end_trim']:
+                        pa.sequence = pa.sequence[int(p['end_trim']):-int(p['end_trim'])]
+                    self.out[r.i] = (pa.sequence, poreseqcpp.swalign(pa.sequence, self.refseqs[r.i], self.native)[0])
+        finally:
+            for r in self.regions:
+                api.align_destroy(r.h)
+                api.rng_destroy(r.rng)
+        return self.out
+
+
+def _run_pool(pool, params, reps, refseqs, logs, workers, batch_size, serialize_native, stats=None, policy=policy_greedy):
+    eng = _Engine(pool, params, reps, refseqs, logs)
+    lock = threading.Condition()
+    native_lock = threading.Lock()
+    state = {"running": 0, "error": None}
+    waiting = [r for r in eng.regions if r.want is not None]
 
     def worker():
         while True:
@@ -170,12 +224,17 @@ def _run_pool(pool, params, reps, refseqs, logs, workers, batch_size, serialize_
                     if state["error"] is not None:
                         return
                     by_kind = {k: [r for r in waiting if r.want == k] for k in _KINDS}
-                    kind = max(_KINDS, key=lambda k: len(by_kind[k]))
-                    if by_kind[kind]:
-                        group = by_kind[kind][:batch_size]
+                    pick = policy(by_kind, state["running"], workers, batch_size)
+                    if pick is None and state["running"] == 0 and waiting:
+                        pick = policy_greedy(by_kind, 0, workers, batch_size)   # nothing in flight to wait for
+                    if pick is not None:
+                        kind, group = pick
                         for r in group:
                             waiting.remove(r)
                         state["running"] += 1
+                        if stats is not None:
+                            c = stats.setdefault(kind, [0, 0])
+                            c[0] += 1; c[1] += len(group)
                         break
                     if state["running"] == 0:
                         lock.notify_all()
@@ -184,12 +243,9 @@ def _run_pool(pool, params, reps, refseqs, logs, workers, batch_size, serialize_
             try:
                 if serialize_native:
                     with native_lock:
-                        res = issue(kind, group)
+                        eng.issue(kind, group)
                 else:
-                    res = issue(kind, group)
-                for r, x in zip(group, res):
-                    r.result = x
-                    advance(r)
+                    eng.issue(kind, group)
             except Exception as e:   # pragma: no cover
                 with lock:
                     state["error"] = e
@@ -207,19 +263,7 @@ def _run_pool(pool, params, reps, refseqs, logs, workers, batch_size, serialize_
     worker()
     for t in threads:
         t.join()
-    try:
-        if state["error"] is not None:
-            raise state["error"]
-        for r in regions:
-            pa = r.pa
-            pa.sequence = api.align_sequence(r.h)
-            api.align_update_events(r.h, pa.events)
-            p = pa.params if params is None else params
-            if 'end_trim' in p and len(pa.sequence) > 2 * p['end_trim']:
-                pa.sequence = pa.sequence[int(p['end_trim']):-int(p['end_trim'])]
-            out[r.i] = (pa.sequence, poreseqcpp.swalign(pa.sequence, refseqs[r.i], native)[0])
-    finally:
-        for r in regions:
-            api.align_destroy(r.h)
-            api.rng_destroy(r.rng)
+    out = eng.finish(ok=state["error"] is None)
+    if state["error"] is not None:
+        raise state["error"]
     return out
