@@ -19,7 +19,7 @@ _KINDS = ("viterbi", "find", "score", "make")   # the native, batchable operatio
 
 
 class _Region:
-    __slots__ = ("i", "pa", "h", "rng", "prog", "want", "arg", "result")
+    __slots__ = ("i", "pa", "h", "rng", "prog", "want", "arg", "result", "phase")   # phase: PSAlign-level calls completed
 
 
 class RegionPool:
@@ -40,7 +40,7 @@ class RegionPool:
                 if len(pa.events) < 5:                      # Mutate.py:50-53
                     continue
                 r = _Region()
-                r.i, r.pa, r.want, r.arg, r.result = i, pa, None, None, None
+                r.i, r.pa, r.want, r.arg, r.result, r.phase = i, pa, None, None, None, 0
                 r.h = self.api.align_create(pa.sequence, pa.events, pa.params)
                 r.rng = self.api.rng_create(1)              # rand() of a fresh process per region (Viterbi.cpp:108)
                 self.regions.append(r)
@@ -103,6 +103,7 @@ class _Engine:
 
     # -- a region's program: the schedule of consensus_region, call by call ---------------------------------------------------
     def _note(self, r, call, nb):
+        r.phase += 1
         if self.logs is not None:
             self.logs[r.i].append((call, nb, r.pa.sequence))
 

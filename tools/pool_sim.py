@@ -56,12 +56,16 @@ def simulate(policy, cohorts=None):
                     mine = [r for r in waiting if cohort_of[r.i] == c]
                     if not mine:
                         continue
-                    kinds = set(r.want for r in mine)
                     alive = [r for r in eng.regions if cohort_of[r.i] == c and r.want is not None]
                     if len(mine) < len(alive):
                         continue                      # members still inside a call
-                    kind = next(k for k in _KINDS if k in kinds)
-                    pick = (kind, [r for r in mine if r.want == kind])
+                    # RegionBatch: one PSAlign-level call at a time for the whole batch — members that have finished it wait
+                    # for the others' rounds; within the call every member still in it is at the same point
+                    first = min(r.phase for r in mine)
+                    group = [r for r in mine if r.phase == first]
+                    kinds = set(r.want for r in group)
+                    assert len(kinds) == 1, kinds
+                    pick = (kinds.pop(), group)
                     busy_cohorts.add(c)
                     break
                 else:
