@@ -10,7 +10,7 @@ import pytest
 import backends as B
 from poreseq_amd import synth
 from poreseq_amd.consensus import consensus_region
-from poreseq_amd.pool import consensus_pool
+from poreseq_amd.pool import consensus_pool, policy_fill, policy_greedy
 from poreseq_amd.util import DEFAULT_PARAMS
 
 P = dict(DEFAULT_PARAMS, verbose=0)
@@ -31,13 +31,13 @@ def _alone(regs):
     return res, logs
 
 
-@pytest.mark.parametrize("workers,batch_size", [(1, 16), (4, 3)])
-def test_pool_equals_regions_refined_alone(workers, batch_size):
+@pytest.mark.parametrize("workers,batch_size,policy", [(1, 16, policy_greedy), (4, 3, policy_greedy), (3, 4, policy_fill)])
+def test_pool_equals_regions_refined_alone(workers, batch_size, policy):
     regs = _regions([(260, 6), (180, 5), (300, 8), (150, 4), (220, 7), (240, 6), (200, 5)], 8100)
     want, wlogs = _alone(regs)
     pas = [B.make_pa(B.OraclePSAlign, d, copy.deepcopy(ev), P) for d, ev, _ in regs]
     logs = [[] for _ in regs]
-    got = consensus_pool(pas, P, logs=logs, workers=workers, batch_size=batch_size, serialize_native=True)   # (the oracle is not re-entrant)
+    got = consensus_pool(pas, P, logs=logs, workers=workers, batch_size=batch_size, policy=policy, serialize_native=True)   # (the oracle is not re-entrant)
     assert logs == wlogs                                 # per call: name, nbases, sequence after the call
     for (w, wra, wrl), g, pa in zip(want, got, pas):
         assert tuple(w) == tuple(g)
