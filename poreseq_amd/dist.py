@@ -57,6 +57,13 @@ def barrier():
         dist.barrier()
 
 
+def finalize():
+    """Barrier + tear-down of the process group (ranks that leave while others still hold gloo / RCCL connections abort)."""
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def max_over_ranks(x):
     if not dist.is_initialized():
         return float(x)
@@ -73,7 +80,8 @@ def gather_regions(local_results, n_regions, max_events):
     with all_gather — RCCL over xGMI under the nccl backend; a few KB per region, latency-bound.
     """
     world = dist.get_world_size() if dist.is_initialized() else 1
-    per = (n_regions + world - 1) // world
+    # rows per rank: the largest share any rank holds (a weighted deal may give one rank more than ceil(n / world) regions)
+    per = max(1, int(max_over_ranks(len(local_results))))
     maxlen = max([len(s) for _, s, _ in local_results] + [0])
     maxlen = int(max_over_ranks(maxlen))
     dev = device()

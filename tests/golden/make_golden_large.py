@@ -16,6 +16,11 @@ Cases (SURVEY.md section 8d / VERDICT round 1 item 1):
   consensus_L1000   full Mutate.py schedule, 1 kb, 10 events (the north_star comparison point)
   consensus_L1500   full schedule, 1.5 kb, 10 events, default widths (bands narrower than the columns)
   consensus_L3000   full schedule, 3 kb, 10 events
+  consensus_L10000_E10   full schedule at BASELINE config #2 size (10 kb, 10 events; ~15-25 min of reference time).  The final
+                    ref_align vectors are stored as int32, the final ref_like vectors as SHA-256 digests (760 KB of random
+                    mantissas otherwise); every intermediate sequence and count is stored
+  mutate_seeds_L10000    one `Mutate(seqs=[4 seed strings], reps=2)` call at 10 kb / 10 events (FindMutations' 5-strip
+                    Smith-Waterman chains and candidate batches with a caller's seed list), then ScoreEvents
 """
 import copy
 import ctypes
@@ -106,7 +111,7 @@ def main():
         print("wrote", name, "%.1f s" % (time.time() - t0), flush=True)
 
     for name, L, E, seed in [("consensus_L1000", 1000, 10, 2201), ("consensus_L1500", 1500, 10, 2202),
-                             ("consensus_L3000", 3000, 10, 2203)]:
+                             ("consensus_L3000", 3000, 10, 2203), ("consensus_L10000_E10", 10000, 10, 2204)]:
         if name not in want:
             continue
         t0 = time.time()
@@ -124,14 +129,40 @@ def main():
         out["calls"] = np.array(calls)
         out["nbases"] = np.array(nb)
         out["sequences"] = np.array(seqs)
+        big = L >= 10000
         for e, ev in enumerate(pa.events):
-            out["final_ev%d_ref_align" % e] = ev.ref_align
-            out["final_ev%d_ref_like" % e] = ev.ref_like
+            if big:   # compact form: int32 alignment (values are integers), digest of the likelihoods
+                assert np.array_equal(ev.ref_align, np.rint(ev.ref_align))
+                out["final_ev%d_ref_align_i32" % e] = ev.ref_align.astype(np.int32)
+                out["final_ev%d_ref_like_sha256" % e] = np.array(hashlib.sha256(np.ascontiguousarray(ev.ref_like, dtype=np.float64).tobytes()).hexdigest())
+            else:
+                out["final_ev%d_ref_align" % e] = ev.ref_align
+                out["final_ev%d_ref_like" % e] = ev.ref_like
         out["final_ScoreEvents"] = np.array(pa.ScoreEvents())
         out["final_accuracy"] = np.array(ref.swalign(pa.sequence, truth)[0])
         out["reference_seconds"] = np.array(time.time() - t0)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print("wrote", name, list(zip(calls, nb)), float(out["final_accuracy"]), "%.1f s" % (time.time() - t0), flush=True)
+
+    if "mutate_seeds_L10000" in want:
+        name, L, E, seed = "mutate_seeds_L10000", 10000, 10, 2205
+        t0 = time.time()
+        libc.srand(1)
+        draft, events, truth = synth.make_region(L, E, seed, ref.swalign, P)
+        out = header(L, E, seed, P, draft, events, truth)
+        rng = np.random.default_rng(seed + 7)
+        seeds = [synth.corrupt(rng, truth, 0.02, 0.02, 0.02) for _ in range(4)]
+        pa = mk(draft, events, P)
+        out["seeds"] = np.array(seeds)
+        out["nbases"] = np.array(pa.Mutate(seqs=list(seeds), reps=2))
+        out["sequence"] = np.array(pa.sequence)
+        for e, ev in enumerate(pa.events):
+            out["final_ev%d_ref_align_i32" % e] = ev.ref_align.astype(np.int32)
+            out["final_ev%d_ref_like_sha256" % e] = np.array(hashlib.sha256(np.ascontiguousarray(ev.ref_like, dtype=np.float64).tobytes()).hexdigest())
+        out["final_ScoreEvents"] = np.array(pa.ScoreEvents())
+        out["reference_seconds"] = np.array(time.time() - t0)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name, int(out["nbases"]), "%.1f s" % (time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":

@@ -38,13 +38,18 @@ if rank == 0:
 '''
 
 
+_PORT_SEQ = 0
+
+
 def run_world(n):
     code = WORKER % {"root": ROOT}
     if n == 1:
         env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
         out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600)
     else:
-        port = 29500 + (os.getpid() % 2000)
+        global _PORT_SEQ
+        _PORT_SEQ += 1
+        port = 29500 + (os.getpid() * 7 + _PORT_SEQ * 13) % 2000   # a fresh port per launch (the previous one may sit in TIME_WAIT)
         out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
                                        "--master-addr", "127.0.0.1", "--master-port", str(port), "-c", code], timeout=900) \
             if False else _torchrun(code, n, port)
@@ -59,9 +64,13 @@ def _torchrun(code, n, port):
         f.write(code)
         path = f.name
     try:
-        return subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-                                        "--master-addr", "127.0.0.1", "--master-port", str(port), path],
-                                       timeout=900, stderr=subprocess.STDOUT)
+        try:
+            return subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                                            "--master-addr", "127.0.0.1", "--master-port", str(port), path],
+                                           timeout=900, stderr=subprocess.STDOUT)
+        except subprocess.CalledProcessError as e:
+            print(e.output.decode(errors="replace")[-4000:])
+            raise
     finally:
         os.unlink(path)
 
@@ -170,3 +179,65 @@ def test_run_regions_in_flight_keeps_order_and_reseeds_per_region():
     assert len(seen) == len(regions) and 1 <= len(set(seen)) <= 3
     seq = psdist.run_regions(regions, process, max_events=4, in_flight=1, fresh_rand=None)
     assert [r[0] for r in seq] == [r[0] for r in out]
+
+
+WORKER_GATHER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+from poreseq_amd import dist as psdist
+rank, local, world = psdist.init(backend="gloo")
+weights = %(weights)r
+items = list(range(len(weights)))
+mine = psdist.shard(items, rank, world, weights=weights)
+local = [(i, "ACGT" * (1 + i %% 5) + "T" * i, np.array([float(i), 2.0 * i])) for i, _ in mine]
+got = psdist.gather_regions(local, len(items), 4)
+share = psdist.max_over_ranks(len(mine))
+if rank == 0:
+    print(json.dumps({"world": world, "share": share, "seqs": [g[0] for g in got], "sc": [g[1][:2].tolist() for g in got]}), flush=True)
+psdist.finalize()
+'''
+
+
+def _gather_world(n, weights):
+    global WORKER
+    keep, WORKER = WORKER, WORKER_GATHER.replace("%(weights)r", repr(weights))
+    try:
+        return run_world(n)
+    finally:
+        WORKER = keep
+
+
+def test_gather_with_skewed_weighted_shares():
+    """ADVICE r2: a weighted deal may hand one rank more than ceil(n / world) regions ([10, 4, 4, 1] on two ranks: 1 + 3);
+    the gather buffers follow the largest share instead of assuming a round-robin split"""
+    w = [10, 4, 4, 1]
+    two = _gather_world(2, w)
+    assert two["world"] == 2 and two["share"] == 3
+    assert two["seqs"] == ["ACGT" * (1 + i % 5) + "T" * i for i in range(4)]
+    assert two["sc"] == [[float(i), 2.0 * i] for i in range(4)]
+
+
+def test_world8_ragged_six_regions_and_gather():
+    """config #4's shape on eight ranks: six regions, two ranks idle; every rank still takes part in the gather"""
+    w = [10000, 10000, 10000, 10000, 10000, 3500]
+    got = _gather_world(8, w)
+    assert got["world"] == 8 and got["share"] == 1
+    assert got["seqs"] == ["ACGT" * (1 + i % 5) + "T" * i for i in range(6)]
+
+
+def test_shard_plan_config5_on_eight_ranks_is_balanced():
+    """config #5: 512 regions (511 of 10 kb + a short tail) dealt to 8 ranks — loads within one region of each other, every
+    region assigned exactly once, the same plan on every rank (pure function, no communication)"""
+    from poreseq_amd import dist as psdist
+    regions = consensus.split_regions(4_600_000, 10000)
+    lens = [b - a for a, b in regions]
+    seen, loads, counts = [], [], []
+    for r in range(8):
+        mine = psdist.shard(regions, r, 8, weights=lens)
+        seen += [i for i, _ in mine]
+        loads.append(sum(b - a for _, (a, b) in mine))
+        counts.append(len(mine))
+    assert sorted(seen) == list(range(len(regions)))
+    assert max(loads) - min(loads) <= max(lens)
+    assert max(counts) - min(counts) <= 1
