@@ -223,7 +223,9 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
                 // slots per anti-diagonal as realign will probably size them (the first chunk finds out and is cut again if not)
                 const int P = std::max(p_seen, guess_slots(a));
                 double add = 0;
-                for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + need[q1].states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0;
+                for (int e = 0; e < a->E; e++)
+                    add += sweep_enabled() && sweep_guess_k(a->par.realign_width) ? fwd_job_bytes(a, a->n[e], (int)need[q1].states.size())
+                                                                                  : ((double)a->n[e] + need[q1].states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0;
                 if (q1 > q0 && (bytes + add > cap || q1 - q0 >= limit)) break;
                 bytes += add; nref += (size_t)a->ntot; q1++;
             }

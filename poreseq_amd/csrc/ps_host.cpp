@@ -588,8 +588,56 @@ int Align::refs_to_host(Runtime* rt) {
 
 // forward fill + backtrace + updaterefs of a batch (the body of ScoreAlignments per event,
 // cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
+bool sweep_enabled() { static const bool off = getenv("PORESEQ_NO_SWEEP") != nullptr; return !off; }
+
+// device bytes one forward-only job of AlignData a (n0 levels against C states) will probably take: step codes of a strip sweep,
+// or the skewed {record, step word} matrix of k_fill
+double fwd_job_bytes(const Align* a, int n0, int C) {
+    const int K = sweep_enabled() ? sweep_guess_k(a->par.realign_width) : 0;
+    if (K) return sweep_job_bytes(n0, C, K);
+    return ((double)n0 + C + 1 + MAT_FRONT + MAT_BACK) * guess_slots(a) * 18.0;
+}
+
+// Forward-only batches (ScoreAlignments): one wave per alignment, one byte per cell (ps_sweep.hip).  Returns -1 when the batch
+// has to take the k_fill path instead (band too wide for 64 strips of any supported height).
+static int realign_sweep(Runtime* rt, Batch& b, double cap) {
+    int W = 0;
+    for (const JobD& j : b.jobs) W = std::max(W, j.W);
+    int K = sweep_guess_k(W);
+    if (const char* e = getenv("PORESEQ_DEBUG_SWEEP_K")) K = atoi(e);   // tests: a given strip height first
+    if (!K) return -1;
+    PS_TRY(launch_begin(rt, b.d));
+    PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
+    for (;;) {
+        PS_TRY(sweep_prepare(rt, b, K));
+        int* w = nullptr;
+        PS_TRY(rt->down(&w, b.sd.maxwin, (size_t)1));
+        PS_HIP(hipStreamSynchronize(rt->stream));
+        { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign (strip sweep): %d jobs, K = %d, widest window %d strips\n", b.d.njobs, K, *w); }
+        if (*w <= sweep_win_max()) break;
+        K = sweep_next_k(K);
+        if (!K) return -1;
+    }
+    if (cap > 0 && (double)b.sweep_code_bytes > cap) { b.P = 0; return PS_SPLIT; }
+    {
+        DBuf& cb = rt->buf("sw_codes");
+        const int rc = cb.ensure((size_t)std::max<int64_t>(b.sweep_code_bytes, 1));
+        if (rc == PS_ERR_NOMEM && cap > 0) { b.P = 0; return PS_SPLIT; }
+        PS_TRY(rc);
+        b.sd.codes = cb.as<unsigned char>();
+    }
+    if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs; }
+    PS_TRY(sweep_run(rt, b));
+    PS_TRY(launch_updaterefs(rt, b.d));
+    return PS_OK;
+}
+
 int realign(Runtime* rt, Batch& b, double cap) {
     if (!b.d.njobs) return PS_OK;
+    if (b.ndir == 1 && sweep_enabled()) {
+        const int rc = realign_sweep(rt, b, cap);
+        if (rc != -1) return rc;
+    }
     PS_TRY(launch_begin(rt, b.d));
     PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
     PS_TRY(launch_lo(rt, b.d, b.ndir, b.maxS));
@@ -659,7 +707,8 @@ static size_t fit_share(const std::vector<Align*>& as, size_t k0, int ndir) {
         const Align* a = as[k];
         const int P = guess_slots(a);
         double add = 0;
-        for (int e = 0; e < a->E; e++) add += ((double)a->n[e] + a->states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0 * ndir;
+        for (int e = 0; e < a->E; e++)
+            add += ndir == 1 ? fwd_job_bytes(a, a->n[e], (int)a->states.size()) : ((double)a->n[e] + a->states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0 * ndir;
         if (k > k0 && bytes + add > cap) break;
         bytes += add;
     }

@@ -41,6 +41,11 @@ struct Batch {
     BatchD d;
     int ndir = 1, P = 0, Pmax = 64, maxC = 0, maxn = 0, maxlbn = 0;
     int64_t maxS = 0, cells = 0, ncols = 0;
+    // strip sweeps (forward-only batches, ps_sweep.hip)
+    std::vector<SweepJob> sjobs;
+    SweepD sd;
+    int sweep_K = 0, sweep_maxT = 0;
+    int64_t sweep_code_bytes = 0, sweep_sb = 0;
     int build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir, int lb_extra);
     int place(Runtime* rt, int P, bool can_split = false);
     double fill_alg_bytes() const;
@@ -81,6 +86,16 @@ struct Align {
 std::vector<int> states_of(const std::string& bases);
 std::string apply_edit(const std::string& b, const Mut& m);
 void accumulate_likes(const double* ra, const double* rl, int n, int C, double* likes);
+
+// strip sweeps (ps_sweep.hip)
+int sweep_guess_k(int W);                         // strip height to try first for realign_width W (0: too wide for a strip sweep)
+int sweep_next_k(int K);                          // next larger one (0: none)
+int sweep_win_max();                              // widest window of strips a sweep supports
+double sweep_job_bytes(int n0, int C, int K);     // bytes of step codes of one job
+int sweep_prepare(Runtime* rt, Batch& b, int K);  // band / qlo tables + the widest window (b.sd.maxwin, device)
+int sweep_run(Runtime* rt, Batch& b);             // sweeps, maxima, backtrace, path scores (b.sd.codes placed by the caller)
+bool sweep_enabled();                             // PORESEQ_NO_SWEEP unset
+double fwd_job_bytes(const Align* a, int n0, int C);   // device bytes one forward-only alignment job will probably take
 
 constexpr int PS_SPLIT = 1;   // realign(): the matrices would exceed `cap` bytes; nothing was launched, b.P holds the width they need
 int realign(Runtime* rt, Batch& b, double cap = 0.0);

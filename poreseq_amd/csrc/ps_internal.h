@@ -149,7 +149,7 @@ struct JobOut {
     int has_index;    // ref_index non-empty after the latest updaterefs
     int refstart, refend;
     int inert;        // latched at the start of an API call: the reference's stripe_width == 0
-    int pad0, pad1;
+    int term_i, term_w;   // where the latest backtrace stopped (bt_walk, ps_dev.h): row; column << 3 | matrix << 2 | kind
 };
 
 constexpr int MODEL_ROW_BYTES = 80;   // k_fill's model rows: 8 doubles + 16 bytes of padding (LDS bank spread)
@@ -171,6 +171,26 @@ struct BatchD {
     int* maxw;                            // widest band footprint of any job of the batch on one anti-diagonal (sizes P)
     int fastdiv;                          // every AlignData of the batch allows k_fill's tabulated reciprocals
     double log2pi;
+};
+
+// ---- strip sweeps (ps_sweep.hip): forward-only alignments, one wave per job ------------------------
+struct StripBest;
+struct SweepJob {           // per job, parallel to BatchD.jobs
+    int64_t codes_off;      // bytes into the code pool: step t of the job starts at codes_off + t * 64 * K
+    int64_t band_off;       // into band (int2 {i0, i1} per column, C + 2 entries)
+    int64_t q_off;          // into qlo (int per step, T + 8 entries)
+    int64_t sb_off;         // into the per-strip maxima (Q entries)
+    int T;                  // steps: t = column + strip runs 1 .. T - 1
+    int Q;                  // strips of K rows
+};
+struct SweepD {
+    const SweepJob* sj;
+    int2* band;
+    int* qlo;
+    unsigned char* codes;   // one byte per cell: main step (3 bits, 7 = implicit) | stay step << 3 | main <= 0 << 5 | stay <= 0 << 6
+    StripBest* sb;
+    int* maxwin;            // widest window of strips in band on one step, over the batch
+    int K;
 };
 
 // ---- kernel launchers (ps_kernels.hip) ------------------------------------------------------
