@@ -180,6 +180,12 @@ int ps_seq_to_states(const char* seq, int64_t n, int32_t* states, int64_t* n_sta
 int ps_debug_fill(ps_align* a, int32_t ev, int32_t direction, double* main, double* stay,
                   uint8_t* step_main, uint8_t* step_stay);
 
+/* Tuning knob (process-wide): forward-only alignment batches — ScoreAlignments, FindMutations' candidate sequences — of at
+ * least `min_alignments` jobs run one wavefront per alignment (ps_sweep.hip); smaller ones a workgroup per alignment (k_fill),
+ * which finishes a lone small batch sooner.  Results do not depend on it.  Negative: back to the default
+ * (PORESEQ_SWEEP_MIN, else 400). */
+int ps_set_sweep_min(int32_t min_alignments);
+
 /* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
  * algorithmic bytes of the named kernel class ("fill", "score", "viterbi", "sw") since reset. */
 /* ps_prof_enable(1) makes every hot-kernel launch be bracketed by HIP events on the library's stream

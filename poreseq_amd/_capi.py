@@ -77,6 +77,7 @@ SYMBOLS = {
                             c_i32p, C.c_int64, c_i64p]),
     "ps_seq_to_states": (C.c_int, [C.c_char_p, C.c_int64, c_i32p, c_i64p]),
     "ps_debug_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_dp, c_dp, c_u8p, c_u8p]),
+    "ps_set_sweep_min": (C.c_int, [C.c_int32]),
     "ps_prof_enable": (C.c_int, [C.c_int32]),
     "ps_prof_reset": (C.c_int, []),
     "ps_prof_get": (C.c_int, [C.c_char_p, c_dp, c_i64p, c_dp]),
@@ -363,6 +364,10 @@ class CApi:
         self.check(self.lib.ps_debug_fill(h, ev, direction, _dp(main), _dp(stay),
                                           sm.ctypes.data_as(c_u8p), ss.ctypes.data_as(c_u8p)))
         return main, stay, sm, ss
+
+    def set_sweep_min(self, n):
+        """forward-only batches of at least n alignments run one wavefront per alignment (negative: the default)"""
+        self.check(self.lib.ps_set_sweep_min(int(n)))
 
     def prof_enable(self, on):
         self.check(self.lib.ps_prof_enable(int(on)))   # 1: synchronous per launch, 2: event pairs queued and read by prof_get

@@ -401,6 +401,31 @@ double device_share_bytes() {
     return std::max(2e9, 0.65 * (double)tot / std::max(4, peak_runtimes()));
 }
 
+// The DP matrices ("rec": 16-byte records, or a strip sweep's step codes, which alias it; "flg": step words) are the only big pools,
+// and several runtimes size theirs at different times (the share depends on how many threads are inside the library).  Two rules
+// keep the sum below the device: a runtime whose pools were sized for a much larger share than today's gives them back before
+// re-sizing, and no matrix pool grows into the last 8 % of the device (small buffers of every runtime live there) — PS_ERR_NOMEM
+// instead, which callers that can split turn into smaller batches.
+static int ensure_matrix_pools(Runtime* rt, size_t need_rec, size_t need_flg, bool can_split) {
+    DBuf& rec = rt->buf("rec");
+    DBuf& flg = rt->buf("flg");
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
+    if (!getenv("PORESEQ_MAX_BATCH_GB") && rec.p && (double)rec.cap > 1.5 * device_share_bytes() + 2e9 && need_rec < rec.cap) {
+        PS_HIP(hipStreamSynchronize(rt->stream));
+        PS_HIP(hipFree(rec.p)); g_pool_bytes -= (long long)rec.cap; rec.p = nullptr; rec.cap = 0;
+        if (flg.p) { PS_HIP(hipFree(flg.p)); g_pool_bytes -= (long long)flg.cap; flg.p = nullptr; flg.cap = 0; }
+    }
+    if (tot && (need_rec > rec.cap || need_flg > flg.cap)) {
+        auto over = [&] { return (double)(g_pool_bytes.load() - (long long)rec.cap - (long long)flg.cap) + (double)need_rec + (double)need_flg > 0.92 * (double)tot; };
+        if (over()) (void)trim_idle_runtimes();
+        if (over() && can_split) return fail(PS_ERR_NOMEM, "the DP matrices of this batch do not fit beside the pools of the other threads' batches");
+    }
+    PS_TRY(rec.ensure(need_rec));
+    if (need_flg) PS_TRY(flg.ensure(need_flg));
+    return PS_OK;
+}
+
 // second phase: the anti-diagonal footprint of every band is known, size the skewed matrices
 int Batch::place(Runtime* rt, int P_, bool can_split) {
     P = std::min(Pmax, std::max(64, ((P_ + 63) / 64) * 64));
@@ -412,29 +437,7 @@ int Batch::place(Runtime* rt, int P_, bool can_split) {
         for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot + (int64_t)MAT_FRONT * P; mat_tot += (j.S + MAT_FRONT + MAT_BACK) * P; }
     }
     cells = mat_tot;
-    {
-        // The matrices are the only big pools, and several runtimes size theirs at different times (the share depends on how many
-        // threads are inside the library).  Two rules keep the sum below the device: a runtime whose pools were sized for a much
-        // larger share than today's gives them back before re-sizing, and no matrix pool grows into the last 8 % of the device
-        // (small buffers of every runtime live there) — PS_ERR_NOMEM instead, which callers that can split turn into smaller batches.
-        DBuf& rec = rt->buf("rec");
-        DBuf& flg = rt->buf("flg");
-        const size_t need_rec = (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(double2), need_flg = (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short);
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
-        if (!getenv("PORESEQ_MAX_BATCH_GB") && rec.p && (double)rec.cap > 1.5 * device_share_bytes() + 2e9 && need_rec < rec.cap) {
-            PS_HIP(hipStreamSynchronize(rt->stream));
-            PS_HIP(hipFree(rec.p)); g_pool_bytes -= (long long)rec.cap; rec.p = nullptr; rec.cap = 0;
-            if (flg.p) { PS_HIP(hipFree(flg.p)); g_pool_bytes -= (long long)flg.cap; flg.p = nullptr; flg.cap = 0; }
-        }
-        if (tot && (need_rec > rec.cap || need_flg > flg.cap)) {
-            auto over = [&] { return (double)(g_pool_bytes.load() - (long long)rec.cap - (long long)flg.cap) + (double)need_rec + (double)need_flg > 0.92 * (double)tot; };
-            if (over()) (void)trim_idle_runtimes();
-            if (over() && can_split) return fail(PS_ERR_NOMEM, "the DP matrices of this batch do not fit beside the pools of the other threads' batches");
-        }
-        PS_TRY(rec.ensure(need_rec));
-        PS_TRY(flg.ensure(need_flg));
-    }
+    PS_TRY(ensure_matrix_pools(rt, (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(double2), (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short), can_split));
     PS_TRY(rt->up(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD)));
     d.rec = rt->buf("rec").as<double2>(); d.flg = rt->buf("flg").as<unsigned short>();
     return PS_OK;
@@ -588,12 +591,17 @@ int Align::refs_to_host(Runtime* rt) {
 
 // forward fill + backtrace + updaterefs of a batch (the body of ScoreAlignments per event,
 // cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
+static int sweep_min_default() { static const int v = getenv("PORESEQ_SWEEP_MIN") ? atoi(getenv("PORESEQ_SWEEP_MIN")) : 400; return v; }
+static std::atomic<int> g_sweep_min(-1);
+void sweep_min_set(int n) { g_sweep_min.store(n); }
 bool sweep_enabled() { static const bool off = getenv("PORESEQ_NO_SWEEP") != nullptr; return !off; }
 
 // device bytes one forward-only job of AlignData a (n0 levels against C states) will probably take: step codes of a strip sweep,
 // or the skewed {record, step word} matrix of k_fill
 double fwd_job_bytes(const Align* a, int n0, int C) {
-    const int K = sweep_enabled() ? sweep_guess_k(a->par.realign_width) : 0;
+    int K = sweep_enabled() ? sweep_guess_k(a->par.realign_width) : 0;
+    static const int dbg = getenv("PORESEQ_DEBUG_SWEEP_K") ? atoi(getenv("PORESEQ_DEBUG_SWEEP_K")) : 0;   // tests: a wrong guess
+    if (K && dbg > 0) K = dbg;
     if (K) return sweep_job_bytes(n0, C, K);
     return ((double)n0 + C + 1 + MAT_FRONT + MAT_BACK) * guess_slots(a) * 18.0;
 }
@@ -618,13 +626,18 @@ static int realign_sweep(Runtime* rt, Batch& b, double cap) {
         K = sweep_next_k(K);
         if (!K) return -1;
     }
-    if (cap > 0 && (double)b.sweep_code_bytes > cap) { b.P = 0; return PS_SPLIT; }
+    if (cap > 0 && (double)b.sweep_code_bytes > cap) {
+        static const bool trace = getenv("PORESEQ_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[ps] realign (strip sweep): %.2f GB of step codes at K = %d, over the share: split\n", b.sweep_code_bytes * 1e-9, K);
+        b.P = 0;
+        return PS_SPLIT;
+    }
     {
-        DBuf& cb = rt->buf("sw_codes");
-        const int rc = cb.ensure((size_t)std::max<int64_t>(b.sweep_code_bytes, 1));
+        // the step codes live in the pool of the score matrices (a runtime runs one batch at a time: never both)
+        const int rc = ensure_matrix_pools(rt, (size_t)std::max<int64_t>(b.sweep_code_bytes, 1), 0, cap > 0);
         if (rc == PS_ERR_NOMEM && cap > 0) { b.P = 0; return PS_SPLIT; }
         PS_TRY(rc);
-        b.sd.codes = cb.as<unsigned char>();
+        b.sd.codes = rt->buf("rec").as<unsigned char>();
     }
     if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs; }
     PS_TRY(sweep_run(rt, b));
@@ -634,7 +647,11 @@ static int realign_sweep(Runtime* rt, Batch& b, double cap) {
 
 int realign(Runtime* rt, Batch& b, double cap) {
     if (!b.d.njobs) return PS_OK;
-    if (b.ndir == 1 && sweep_enabled()) {
+    // forward-only batches take the strip sweep (one wave per alignment) from ps_set_sweep_min / PORESEQ_SWEEP_MIN alignments on
+    // (default 400); a smaller batch alone on the chip finishes sooner with a workgroup per alignment (k_fill: ~11 ms against
+    // ~25 ms for a 10 kb sweep; with several batches in flight the two take the same time)
+    const int sweep_min = g_sweep_min.load() >= 0 ? g_sweep_min.load() : sweep_min_default();
+    if (b.ndir == 1 && sweep_enabled() && b.d.njobs >= sweep_min) {
         const int rc = realign_sweep(rt, b, cap);
         if (rc != -1) return rc;
     }
@@ -958,8 +975,6 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     stage.reserve(ints);
     auto push = [&](const std::vector<int>& v) { int* r = dp + stage.size(); stage.insert(stage.end(), v.begin(), v.end()); return r; };
     std::vector<ScoreArgs> sas(R);
-    std::vector<std::array<const int*, 4>> cls_items(R);
-    std::vector<std::array<int, 4>> cls_count(R);
     for (int k = 0; k < R; k++) {
         const EditPlan& p = plan[k];
         ScoreArgs& sa = sas[k];
@@ -968,7 +983,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         sa.nitems_per_job = p.M; sa.ncolmax = p.ncolmax; sa.ws = as[k]->par.scoring_width; sa.nr0 = p.nr0;
         sa.m_start = push(p.start); sa.m_mlen = push(p.mlen); sa.m_cm = push(p.cm); sa.m_ncol = push(p.ncol);
         sa.m_skip = push(p.skip); sa.m_oldidx = push(p.oldidx); sa.m_states = push(p.states); sa.r0 = push(p.r0s);
-        for (int q = 0; q < 4; q++) { cls_items[k][q] = push(p.cls[q]); cls_count[k][q] = (int)p.cls[q].size(); }
+        for (int q = 0; q < 4; q++) { sa.cls_items[q] = push(p.cls[q]); sa.cls_count[q] = (int)p.cls[q].size(); }
         sa.old = dd; dd += (size_t)as[k]->E * std::max(p.nr0, 1);
         sa.delta = dd; dd += (size_t)as[k]->E * std::max(p.M, 1);
         sa.score = dd; dd += std::max(p.M, 1);
@@ -976,9 +991,14 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         sa.oldall_pitch = (int64_t)as[k]->states.size() + 8;
         sa.maxS = b.maxS;
         sa.oldall = (size_t)p.nr0 * 4 > as[k]->states.size() && p.nr0 >= 256 ? dd : nullptr;
+        if (sa.oldall) PS_HIP(hipMemsetAsync(sa.oldall, 0, (size_t)as[k]->E * sa.oldall_pitch * sizeof(double), rt->stream));
         dd += (size_t)as[k]->E * sa.oldall_pitch;
+        if (!p.M || !as[k]->E) { sa.njobs = 0; sa.nitems_per_job = 0; }   // nothing to score for this AlignData: its blocks leave at once
     }
     PS_TRY(rt->up(dp, stage.data(), stage.size() * sizeof(int)));
+    DBuf& sab = rt->buf("scoreargs");
+    PS_TRY(sab.ensure((size_t)R * sizeof(ScoreArgs)));
+    PS_TRY(rt->up(sab.p, sas.data(), (size_t)R * sizeof(ScoreArgs)));
     tk.lap("upload");
     if (tk.on) { PS_HIP(hipStreamSynchronize(rt->stream)); }
     tk.lap("realign fwd+back (rest)");
@@ -996,9 +1016,10 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
             rt->prof["score"].bytes += t * as[k]->E;
             rt->prof["score"].units += (double)p.M * as[k]->E;
         }
-        PS_TRY(launch_score(rt, b.d, sas[k], cls_items[k].data(), cls_count[k].data()));
-        PS_TRY(rt->down(&sc[k], sas[k].score, (size_t)p.M));
     }
+    PS_TRY(launch_score(rt, b.d, sab.as<ScoreArgs>(), sas));
+    for (int k = 0; k < R; k++)
+        if (plan[k].M && as[k]->E) PS_TRY(rt->down(&sc[k], sas[k].score, (size_t)plan[k].M));
     PS_HIP(hipStreamSynchronize(rt->stream));
     for (int k = 0; k < R; k++)
         if (sc[k]) for (int i = 0; i < plan[k].M; i++) (*outs[k])[i].score = sc[k][i];
@@ -1047,13 +1068,23 @@ static int greedy_apply(Align* a, std::vector<Mut>& muts, std::vector<Mut>* late
     int nb = 0;
     later->clear();
     {
-        // std::sort on indices makes exactly the comparisons (hence the same permutation, ties included) it would
-        // make on the structs themselves, without moving two std::strings per swap
-        std::vector<int> order(muts.size());
-        std::iota(order.begin(), order.end(), 0);
+        // The reference sorts the whole list by descending score and drops the negative tail (cpp/MakeMutations.cpp:80-86).  When
+        // the scores that survive (>= 0) are pairwise different — the normal case: a Refine list is 80 000 edits of which a few
+        // hundred are positive — their order does not depend on how the rest was permuted, so only they are sorted.  Equal scores
+        // among them are ordered by std::sort's own permutation of the WHOLE list, which is then reproduced (index sort: the same
+        // comparisons as on the structs, without moving two std::strings per swap).
+        std::vector<int> order;
+        for (int k = 0; k < (int)muts.size(); k++) if (!(muts[k].score < 0)) order.push_back(k);
         const std::vector<Mut>& mref = muts;
         std::sort(order.begin(), order.end(), [&](int x, int y) { return by_score_desc(mref[x], mref[y]); });
-        while (!order.empty() && muts[order.back()].score < 0) order.pop_back();
+        bool ties = false;
+        for (size_t k = 1; k < order.size(); k++) if (muts[order[k - 1]].score == muts[order[k]].score) { ties = true; break; }
+        if (ties || order.size() == muts.size()) {
+            order.resize(muts.size());
+            std::iota(order.begin(), order.end(), 0);
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return by_score_desc(mref[x], mref[y]); });
+            while (!order.empty() && muts[order.back()].score < 0) order.pop_back();
+        }
         std::vector<Mut> kept;
         kept.reserve(order.size());
         for (int k : order) kept.push_back(std::move(muts[k]));

@@ -94,6 +94,7 @@ int sweep_win_max();                              // widest window of strips a s
 double sweep_job_bytes(int n0, int C, int K);     // bytes of step codes of one job
 int sweep_prepare(Runtime* rt, Batch& b, int K);  // band / qlo tables + the widest window (b.sd.maxwin, device)
 int sweep_run(Runtime* rt, Batch& b);             // sweeps, maxima, backtrace, path scores (b.sd.codes placed by the caller)
+void sweep_min_set(int n);                        // forward-only batches of at least n alignments take the strip sweep (< 0: default)
 bool sweep_enabled();                             // PORESEQ_NO_SWEEP unset
 double fwd_job_bytes(const Align* a, int n0, int C);   // device bytes one forward-only alignment job will probably take
 

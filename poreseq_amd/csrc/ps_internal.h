@@ -219,9 +219,10 @@ struct ScoreArgs {
     int64_t oldall_pitch, maxS;
     double* delta;             // [njobs][M]
     double* score;             // [M]
+    const int* cls_items[4];   // device lists of edit indices whose new-column count fits 8 << k lanes (k = 3: chunked, any size)
+    int cls_count[4];
 };
-// cls_items[k]: device list of edit indices whose new-column count fits 8 << k lanes (k = 3: chunked, any size)
-int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* const cls_items[4], const int cls_count[4]);
+int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs* d_sas, const std::vector<ScoreArgs>& h_sas);
 int launch_begin(Runtime* rt, const BatchD& b);
 
 // Smith-Waterman (ps_sw.hip)

@@ -829,7 +829,9 @@ __device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, 
 }
 
 // old score for each distinct r0 = max(start - 3, 1) ; grid (nr0, njobs), block 64
-__global__ __launch_bounds__(64) void k_old(BatchD b, ScoreArgs a) {
+__global__ __launch_bounds__(64) void k_old(BatchD b, const ScoreArgs* __restrict__ A) {
+    const ScoreArgs& a = A[blockIdx.z];
+    if (a.oldall || (int)blockIdx.x >= a.nr0 || (int)blockIdx.y >= a.njobs) return;
     const JobD& J = b.jobs[a.job0 + blockIdx.y];
     if (J.out->inert) return;
     const int r0 = a.r0[blockIdx.x];
@@ -847,9 +849,11 @@ __global__ __launch_bounds__(64) void k_old(BatchD b, ScoreArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int OA_SB = 32;      // anti-diagonals per block
 constexpr int OA_COLS = 2048;  // column window of a block in LDS
-__global__ __launch_bounds__(256) void k_oldall(BatchD b, ScoreArgs a) {
+__global__ __launch_bounds__(256) void k_oldall(BatchD b, const ScoreArgs* __restrict__ A) {
     __shared__ unsigned long long s_max[OA_COLS];
     __shared__ int s_jbase, s_ok;
+    const ScoreArgs& a = A[blockIdx.z];
+    if (!a.oldall || !a.nr0 || (int)blockIdx.y >= a.njobs) return;
     const JobD& J = b.jobs[a.job0 + blockIdx.y];
     if (J.out->inert) return;
     const int s0 = blockIdx.x * OA_SB;
@@ -916,7 +920,9 @@ __global__ __launch_bounds__(256) void k_oldall(BatchD b, ScoreArgs a) {
 }
 
 // old[r0] = max(0, column sums, forward MaxInfo up to r0, backward MaxInfo up to C - r0 + 1)  (cpp/Alignment.h:181-214); grid (ceil(nr0/256), njobs)
-__global__ __launch_bounds__(256) void k_oldfin(BatchD b, ScoreArgs a) {
+__global__ __launch_bounds__(256) void k_oldfin(BatchD b, const ScoreArgs* __restrict__ A) {
+    const ScoreArgs& a = A[blockIdx.z];
+    if (!a.oldall || (int)blockIdx.y >= a.njobs) return;
     const JobD& J = b.jobs[a.job0 + blockIdx.y];
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= a.nr0 || J.out->inert) return;
@@ -938,8 +944,13 @@ __global__ __launch_bounds__(256) void k_oldfin(BatchD b, ScoreArgs a) {
 // (at most 96 VGPRs — five waves per SIMD: with 100 a workgroup's wave did not fit beside the two 208-register waves a lone k_fill
 //  sweep keeps on SIMD 0 and 1, so k_score ran only on CUs without a fill: 1.07 ms per launch in the bench against 0.25 ms alone)
 template <int G, bool FD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_score(BatchD b, ScoreArgs a, const int* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_score(BatchD b, const ScoreArgs* __restrict__ A) {
     constexpr int IPW = 64 / G;
+    constexpr int CLS = G == 8 ? 0 : (G == 16 ? 1 : (G == 32 ? 2 : 3));
+    const ScoreArgs& a = A[blockIdx.z];
+    const int nitems = a.cls_count[CLS];
+    if ((int)blockIdx.y >= a.njobs || (int)blockIdx.x * 4 * IPW >= nitems) return;
+    const int* __restrict__ items = a.cls_items[CLS];
     __shared__ double s_carry[(G == 64) ? 4 * 1024 : 1];   // last column of a 64-column chunk, per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / G, c = lane % G;
@@ -1085,7 +1096,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 }
 
 // score[m] = -1e-6 + sum over events in order (cpp/AlignUtil.h:86, cpp/MakeMutations.cpp:51)
-__global__ void k_reduce(ScoreArgs a, int njobs) {
+__global__ void k_reduce(const ScoreArgs* __restrict__ A) {
+    const ScoreArgs& a = A[blockIdx.y];
+    const int njobs = a.njobs;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= a.nitems_per_job) return;
     double s = -1e-6;
@@ -1246,33 +1259,46 @@ int launch_begin(Runtime* rt, const BatchD& b) {
     return PS_OK;
 }
 
-int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs& a, const int* const cls_items[4], const int cls_count[4]) {
-    const int njobs = a.njobs;   // the jobs [a.job0, a.job0 + njobs) of the batch belong to the AlignData being scored
-    if (!njobs || !a.nitems_per_job) return PS_OK;
-    if (a.nr0 > 0 && a.oldall) {
+// edit scoring of several AlignData of one batch (d_sas: their ScoreArgs on the device, h_sas the same on the host): one launch
+// per kernel over all of them — grid.z (k_reduce: grid.y) is the AlignData, blocks past an AlignData's own sizes leave at once
+int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs* d_sas, const std::vector<ScoreArgs>& h_sas) {
+    const int R = (int)h_sas.size();
+    int maxE = 0, maxnr0 = 0, maxnr0_all = 0, maxM = 0, cls_max[4] = {0, 0, 0, 0};
+    int64_t maxS = 0;
+    bool any_all = false, any_old = false;
+    for (const ScoreArgs& a : h_sas) {
+        if (!a.njobs || !a.nitems_per_job) continue;
+        maxE = std::max(maxE, a.njobs); maxM = std::max(maxM, a.nitems_per_job);
+        if (a.nr0 > 0 && a.oldall) { any_all = true; maxS = std::max(maxS, a.maxS); maxnr0_all = std::max(maxnr0_all, a.nr0); }
+        else if (a.nr0 > 0) { any_old = true; maxnr0 = std::max(maxnr0, a.nr0); }
+        for (int k = 0; k < 4; k++) cls_max[k] = std::max(cls_max[k], a.cls_count[k]);
+    }
+    if (!maxE || !maxM) return PS_OK;
+    if (any_all) {
         // a list that touches most columns (Refine, ScorePoints): one coalesced pass over both matrices serves every position
-        PS_HIP(hipMemsetAsync(a.oldall, 0, (size_t)njobs * a.oldall_pitch * sizeof(double), rt->stream));
-        hipLaunchKernelGGL(k_oldall, dim3((unsigned)((a.maxS + OA_SB - 1) / OA_SB), njobs), dim3(256), 0, rt->stream, b, a);
-        hipLaunchKernelGGL(k_oldfin, dim3((a.nr0 + 255) / 256, njobs), dim3(256), 0, rt->stream, b, a);
+        // (the caller has zeroed the oldall arrays)
+        hipLaunchKernelGGL(k_oldall, dim3((unsigned)((maxS + OA_SB - 1) / OA_SB), maxE, R), dim3(256), 0, rt->stream, b, d_sas);
+        hipLaunchKernelGGL(k_oldfin, dim3((maxnr0_all + 255) / 256, maxE, R), dim3(256), 0, rt->stream, b, d_sas);
         PS_LAUNCH_CHECK();
-    } else if (a.nr0 > 0) {
-        hipLaunchKernelGGL(k_old, dim3(a.nr0, njobs), dim3(64), 0, rt->stream, b, a);
+    }
+    if (any_old) {
+        hipLaunchKernelGGL(k_old, dim3(maxnr0, maxE, R), dim3(64), 0, rt->stream, b, d_sas);
         PS_LAUNCH_CHECK();
     }
     prof_begin(rt);
     for (int k = 0; k < 4; k++) {
-        const int n = cls_count[k];
+        const int n = cls_max[k];
         if (!n) continue;
         const int G = 8 << k, ipb = 4 * (64 / G);
-        dim3 grid((n + ipb - 1) / ipb, njobs), block(256);
-#define PS_SCORE(GG) do { if (b.fastdiv) hipLaunchKernelGGL((k_score<GG, true>), grid, block, 0, rt->stream, b, a, cls_items[k], n); \
-                          else hipLaunchKernelGGL((k_score<GG, false>), grid, block, 0, rt->stream, b, a, cls_items[k], n); } while (0)
+        dim3 grid((n + ipb - 1) / ipb, maxE, R), block(256);
+#define PS_SCORE(GG) do { if (b.fastdiv) hipLaunchKernelGGL((k_score<GG, true>), grid, block, 0, rt->stream, b, d_sas); \
+                          else hipLaunchKernelGGL((k_score<GG, false>), grid, block, 0, rt->stream, b, d_sas); } while (0)
         if (k == 0) PS_SCORE(8); else if (k == 1) PS_SCORE(16); else if (k == 2) PS_SCORE(32); else PS_SCORE(64);
 #undef PS_SCORE
         PS_LAUNCH_CHECK();
     }
     prof_end(rt, "score", 0.0);
-    hipLaunchKernelGGL(k_reduce, dim3((a.nitems_per_job + 255) / 256), dim3(256), 0, rt->stream, a, njobs);
+    hipLaunchKernelGGL(k_reduce, dim3((maxM + 255) / 256, R), dim3(256), 0, rt->stream, d_sas);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }

@@ -116,11 +116,16 @@ def test_hip_seed_chunks_are_cut_again_when_the_bands_are_wider_than_guessed():
         assert r.returncode == 0, r.stderr[-2000:]
         return [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0], r.stderr
     want, err0 = run({})
-    got, err1 = run({"PORESEQ_DEBUG_GUESS_P": "64", "PORESEQ_MAX_BATCH_GB": "0.2"})
+    got, err1 = run({"PORESEQ_DEBUG_GUESS_P": "64", "PORESEQ_MAX_BATCH_GB": "0.2", "PORESEQ_NO_SWEEP": "1"})   # k_fill's matrices
     assert "cut again" not in err0 and "over the share" not in err0 and "the rest in chunks" not in err0
     assert "cut again" in err1           # FindMutations' candidate batches
     assert "over the share" in err1      # the lock-step realigns of ScoreAlignments / ScoreMutations
     assert got == want
+    # the strip sweep (forward-only batches): a strip height too small for the band is raised, code pools over the share are split
+    got3, err3 = run({"PORESEQ_DEBUG_SWEEP_K": "4", "PORESEQ_MAX_BATCH_GB": "0.02", "PORESEQ_SWEEP_MIN": "0"})
+    assert "K = 4," in err3 and ("K = 6," in err3 or "K = 10," in err3) and "of step codes" in err3
+    assert got3 == want
+    assert run({"PORESEQ_SWEEP_MIN": "0"})[0] == want    # both kernels: the same results
     got2, err2 = run({"PORESEQ_MAX_BATCH_GB": "0.002"})
     assert "the rest in chunks" in err2  # Smith-Waterman batches larger than an eighth of the share
     assert got2 == want

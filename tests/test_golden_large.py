@@ -4,6 +4,8 @@
                                 on a 10 kb region with 10 / 30 events (config #2 / one region of config #3)
   consensus_L1000/L1500/L3000   the full Mutate.py schedule (per-call nbases, the sequence after every call, final
                                 ref_align / ref_like of every event, final ScoreEvents)
+  consensus_L10000_E10          the same at BASELINE config #2's size (final ref_like vectors as digests)
+  mutate_seeds_L10000           one Mutate(list of seed strings) call at 10 kb
 
 Inputs are regenerated from the fixture's seed and verified by checksum; every comparison is bit-exact (tolerance 0).
 The oracle runs the cheaper cases on CPU (`not gpu`); the HIP library runs all of them (`gpu`).
@@ -46,9 +48,32 @@ def _schedule_case(cls, sw, name):
             got = pa.Refine()
         assert got == int(nb), (name, call)
         assert pa.sequence == str(seq), (name, call)
+    _final_refs(pa, z, name)
+    assert np.array_equal(np.array(pa.ScoreEvents()), z["final_ScoreEvents"])
+
+
+def _final_refs(pa, z, name):
+    """final ref_align / ref_like of every event: stored in full, or (10 kb fixtures) as int32 alignment + SHA-256 of the likelihoods"""
+    import hashlib
     for e, ev in enumerate(pa.events):
-        assert np.array_equal(ev.ref_align, z["final_ev%d_ref_align" % e]), (name, e)
-        assert np.array_equal(ev.ref_like, z["final_ev%d_ref_like" % e]), (name, e)
+        if "final_ev%d_ref_align" % e in z.files:
+            assert np.array_equal(ev.ref_align, z["final_ev%d_ref_align" % e]), (name, e)
+            assert np.array_equal(ev.ref_like, z["final_ev%d_ref_like" % e]), (name, e)
+        else:
+            assert np.array_equal(ev.ref_align, z["final_ev%d_ref_align_i32" % e].astype(np.float64)), (name, e)
+            got = hashlib.sha256(np.ascontiguousarray(ev.ref_like, dtype=np.float64).tobytes()).hexdigest()
+            assert got == str(z["final_ev%d_ref_like_sha256" % e]), (name, e)
+
+
+def _seed_list_case(cls, sw, name):
+    """one Mutate(seqs=[caller's seed strings], reps=2) at 10 kb: Smith-Waterman strip chains, candidate batches, greedy application"""
+    z = G.load(name)
+    draft, events, truth, par = G.regen(z, sw)
+    B.reset_rand()
+    pa = B.make_pa(cls, draft, copy.deepcopy(events), par)
+    got = pa.Mutate(seqs=[str(s) for s in z["seeds"]], reps=2)
+    assert got == int(z["nbases"]) and pa.sequence == str(z["sequence"])
+    _final_refs(pa, z, name)
     assert np.array_equal(np.array(pa.ScoreEvents()), z["final_ScoreEvents"])
 
 
@@ -61,6 +86,11 @@ def test_oracle_consensus_L1000_golden():
     _schedule_case(B.OraclePSAlign, B.oracle_swalign, "consensus_L1000")
 
 
+def test_oracle_mutate_seed_list_10kb_golden():
+    """pins the oracle's FindMutations / Smith-Waterman / greedy loop at 10 kb against the reference's own run (~40 s)"""
+    _seed_list_case(B.OraclePSAlign, B.oracle_swalign, "mutate_seeds_L10000")
+
+
 # ---- GPU: the HIP library against the same vectors -------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["score10k_E10", "score10k_E30"])
@@ -69,6 +99,26 @@ def test_hip_score10k_golden(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["consensus_L1000", "consensus_L1500", "consensus_L3000"])
-def test_hip_consensus_schedule_golden(name):
+@pytest.mark.parametrize("name", ["consensus_L1000", "consensus_L1500", "consensus_L3000", "consensus_L10000_E10"])
+def test_hip_consensus_schedule_golden(name, sweep_always):
+    """the full Mutate.py:62-93 schedule against the reference's own run — up to BASELINE config #2's size (10 kb, 10 events:
+    18 minutes of reference time) — with every forward-only batch on the strip sweep"""
     _schedule_case(PSAlign, swalign, name)
+
+
+@pytest.mark.gpu
+def test_hip_consensus_10kb_golden_default_kernels():
+    """the same 10 kb schedule with the default kernel choice (a lone region's batches are below the strip sweep's threshold)"""
+    _schedule_case(PSAlign, swalign, "consensus_L10000_E10")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sweep", "default"])
+def test_hip_mutate_seed_list_10kb_golden(mode):
+    from poreseq_amd import _capi
+    api = _capi.load_hip()
+    api.set_sweep_min(0 if mode == "sweep" else -1)
+    try:
+        _seed_list_case(PSAlign, swalign, "mutate_seeds_L10000")
+    finally:
+        api.set_sweep_min(-1)

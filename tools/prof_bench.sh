@@ -9,6 +9,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$TAG -o r -- pyt
 grep '^{' /tmp/pb_$TAG.log | tail -1 | cut -c1-160
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof
 cp $(find /tmp/pb_$TAG -name '*kernel_stats.csv' | head -1) $GRAFT_REPO_ROOT/gpurun_out/prof/${TAG}_kernel_stats.csv
+cut -d, -f8-12,14- $(find /tmp/pb_$TAG -name '*kernel_trace.csv' | head -1) | gzip > $GRAFT_REPO_ROOT/gpurun_out/prof/${TAG}_trace.csv.gz   # (queue, kernel, times, grid: for offline timelines)
 python3 - $(find /tmp/pb_$TAG -name '*kernel_trace.csv' | head -1) /tmp/pb_$TAG.log <<'PY'
 import csv, sys, json, collections
 rows = []
@@ -29,9 +30,9 @@ print("timed step %.0f ms: %d kernels, sum of durations %.0f ms, no kernel in fl
 for n, v in tot.most_common(12): print("  %-26s %5d launches %9.1f ms  avg %8.1f us" % (n[:26], cnt[n], v / 1e6, v / cnt[n] / 1e3))
 h = collections.defaultdict(lambda: [0, 0])
 for s, e, n, g in rows:
-    if n.startswith("k_fill<"):
+    if n.startswith("k_fill<") or n.startswith("k_sweep<"):
         b = 1
         while b < g: b *= 2
         h[b][0] += 1; h[b][1] += e - s
-print("k_fill launches by workgroups (<= bucket): " + "  ".join("%d: %d x %.1f ms" % (b, c, d / c / 1e6) for b, (c, d) in sorted(h.items())))
+print("k_fill / k_sweep launches by workgroups (<= bucket): " + "  ".join("%d: %d x %.1f ms" % (b, c, d / c / 1e6) for b, (c, d) in sorted(h.items())))
 PY
