@@ -8,10 +8,11 @@ parallelism (one process per region file, README.md:48-54).  One GPU refines the
 batches (poreseq_amd.batch / the ps_batch_* entry points; one host thread and one stream per batch): every phase of the
 schedule is one launch chain over all of a batch's events, with the default HIP environment (no extra hardware queues,
 no per-region threads or streams).  Default: 140 regions as 7 batches of 20.
-The events of a step's regions are resident in HBM when the clock starts (RegionBatch.load: the marshalling + H2D copy
-a PSAlign call would do); DESIGN.md section 7 gives the PCIe-inclusive rate.  With N GPUs every rank refines its own
-batch per step (weak scaling, no data-path collective) and the value is the whole-job rate
-N * R * region_kb * K / max-over-ranks time.
+The clock covers what SURVEY.md section 8(d) defines as the metric: marshalling of the events + H2D (RegionBatch.load, the copy a
+PSAlign call does, once per region), the whole schedule incl. the host's greedy steps, and D2H of sequences and alignments; the
+synthetic data are generated outside it.  `resident` in the JSON line is the same measurement with the load left out of the
+clock (what the rules call the kernel-side figure).  With N GPUs every rank refines its own batch per step (weak scaling, no
+data-path collective) and the value is the whole-job rate N * R * region_kb * K / max-over-ranks time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--length L] [--events E] [--regions-per-gpu R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -100,10 +101,6 @@ def main():
     ap.add_argument("--batches-in-flight", type=int, default=7,
                     help="lock-step batches per GPU (one host thread each): while one batch is in a thin phase or on the host, "
                          "the others keep the GPU full; the regions of a step are dealt round-robin to the batches")
-    ap.add_argument("--scheduler", choices=["lock-step", "pool"], default="lock-step",
-                    help="lock-step: the regions of a step as B fixed batches (the measured default).  pool (experimental, "
-                         "poreseq_amd.pool): regions advance independently, B worker threads issue whichever native operation "
-                         "most regions wait for, for up to R/B regions at a time")
     ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip everything that touches the CPU checkers (oracle / reference)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-region, 1 kb and profiled passes (profiling runs)")
@@ -145,24 +142,13 @@ def main():
 
     live_prof = []   # per timed step: {class: [ms, launches, bytes, units]} summed over the step's host threads
 
+    load_s = []      # per timed step: seconds of the step spent marshalling + copying the events to the device (inside the clock)
+
     def run_batch(regs, timed=False, nb=1):
-        """one step: the regions dealt to `nb` lock-step batches, one host thread each; the clock (when timed) starts with
-        every batch's events resident in HBM"""
+        """one step: the regions dealt to `nb` lock-step batches, one host thread each; the clock (when timed) starts BEFORE
+        the events are marshalled and copied to the device"""
         import threading
         nb = max(1, min(nb, len(regs)))
-        if args.scheduler == "pool" and nb > 1:
-            from poreseq_amd.pool import RegionPool
-            allpas = [as_pa(r) for r in regs]
-            pool = RegionPool(allpas).load()
-            if timed:
-                psdist.barrier()
-                if torch.cuda.is_available():
-                    torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            res = pool.run(params, workers=nb, batch_size=max(1, len(regs) // nb))
-            if timed and torch.cuda.is_available():
-                torch.cuda.synchronize()
-            return time.perf_counter() - t0, res
         groups = [regs[k::nb] for k in range(nb)]
         pas = [[as_pa(r) for r in g] for g in groups]
         rbs = [RegionBatch(p) for p in pas]
@@ -199,17 +185,19 @@ def main():
             if errs:
                 raise errs[0]
 
-        fan(load)           # each thread creates its own batch's AlignData: the library's runtimes are per host thread
         if timed:
             psdist.barrier()
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
         t0 = time.perf_counter()
+        fan(load)           # each thread creates its own batch's AlignData: the library's runtimes are per host thread
+        t1 = time.perf_counter()
         fan(work)
         if timed and torch.cuda.is_available():
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if timed:
+            load_s.append(t1 - t0)
             live_prof.append({c: [sum(p[c][i] for p in profs if p) for i in range(4)] for c in KERNEL_OF})
         out = [None] * len(regs)
         for k in range(nb):
@@ -251,6 +239,7 @@ def main():
         t, last = run_batch(regions[s], timed=True, nb=NB)
         dt += t
     psdist.barrier()
+    dt_res = psdist.max_over_ranks(dt - sum(load_s))
     dt = psdist.max_over_ranks(dt)
     kb = args.length / 1000.0
     value = world * R * kb * args.steps / dt
@@ -260,12 +249,16 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / max(args.steps, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "poreseq consensus, %d kb region, %dx synthetic coverage (BASELINE configs[1]), full Mutate.py "
-                               "schedule per region; a step is %d independent regions per GPU, refined as %d lock-step batches "
-                               "(events resident in HBM when the clock starts)" % (args.length // 1000, args.events, R, NB),
+                               "schedule per region; a step is %d independent regions per GPU, refined as %d lock-step batches; "
+                               "marshalling + H2D of the events, host greedy steps and D2H inside the clock"
+                               % (args.length // 1000, args.events, R, NB),
                    "region_bases": args.length, "events": args.events, "regions_per_gpu": R, "batches_in_flight": NB,
-                   "scheduler": args.scheduler,
                    "parallelism": "%d regions x %d GPU(s), %d host thread(s) per GPU, no data-path collective" % (R, world, NB)},
     }
+
+    out["resident"] = {"value": world * R * kb * args.steps / dt_res, "unit": "kb/s", "ms_per_step": 1000.0 * dt_res / max(args.steps, 1),
+                       "load_ms_per_step": 1000.0 * sum(load_s) / max(args.steps, 1),
+                       "note": "the same steps with the events' marshalling + H2D left out of the clock (not the metric's definition)"}
 
     if rank == 0:
         a0 = swalign(regions[-1][0][0], regions[-1][0][2])[0]
@@ -360,8 +353,20 @@ def main():
                     ns["cpu_reference_s"] = cpu_pre["t1k"]
                     ns["speedup_single_region"] = cpu_pre["t1k"] / ns["single_region_s"]
                     ns["speedup_lock_step"] = ns["lock_step_kb_s"] * cpu_pre["t1k"]
+            try:   # one MEASURED run of the reference's full schedule at this size (tests/golden/make_golden_large.py, build container, one core)
+                import numpy as np
+                z = np.load(os.path.join(ROOT, "tests", "golden", "consensus_L10000_E10.npz"), allow_pickle=False)
+                if int(z["L"]) == args.length and int(z["E"]) == args.events:
+                    rs = float(z["reference_seconds"])
+                    cpu["measured_full_schedule_same_size"] = {
+                        "seconds": rs, "value": kb / rs, "unit": "kb/s", "cores": 1,
+                        "where": "build container (8-core host), the reference's Cython PSAlign, one region of %d bases x %d events; "
+                                 "the fixture the -m gpu test test_hip_consensus_schedule_golden[consensus_L10000_E10] replays" % (args.length, args.events)}
+            except (OSError, KeyError, ValueError):
+                pass
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
+    psdist.finalize()
 
 
 if __name__ == "__main__":

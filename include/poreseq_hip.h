@@ -37,7 +37,7 @@ typedef enum ps_status {
     PS_ERR_BAD_ARG = -1,     /* NULL pointer, negative size, negative mutation start ... */
     PS_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init */
     PS_ERR_HIP = -3,         /* a HIP call failed */
-    PS_ERR_UNSUPPORTED = -4, /* e.g. realign_width > 510 (band wider than one workgroup) */
+    PS_ERR_UNSUPPORTED = -4, /* e.g. a band footprint beyond 2046 rows on one anti-diagonal (realign_width > 1022 in the worst case) */
     PS_ERR_NOMEM = -5
 } ps_status;
 
@@ -185,6 +185,10 @@ int ps_debug_fill(ps_align* a, int32_t ev, int32_t direction, double* main, doub
  * which finishes a lone small batch sooner.  Results do not depend on it.  Negative: back to the default
  * (PORESEQ_SWEEP_MIN, else 400). */
 int ps_set_sweep_min(int32_t min_alignments);
+/* The same for Alignment::update batches (ScoreMutations: a forward and a backward sweep per alignment, with score matrices):
+ * from `min_sweeps` sweeps on, one wavefront per sweep.  Negative: the default (PORESEQ_SWEEP2_MIN, else never:
+ * their records cap a launch at a few hundred sweeps, where a workgroup per sweep is twice as fast — DESIGN.md section 4). */
+int ps_set_sweep2_min(int32_t min_sweeps);
 
 /* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
  * algorithmic bytes of the named kernel class ("fill", "score", "viterbi", "sw") since reset. */

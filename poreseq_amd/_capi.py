@@ -78,6 +78,7 @@ SYMBOLS = {
     "ps_seq_to_states": (C.c_int, [C.c_char_p, C.c_int64, c_i32p, c_i64p]),
     "ps_debug_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_dp, c_dp, c_u8p, c_u8p]),
     "ps_set_sweep_min": (C.c_int, [C.c_int32]),
+    "ps_set_sweep2_min": (C.c_int, [C.c_int32]),
     "ps_prof_enable": (C.c_int, [C.c_int32]),
     "ps_prof_reset": (C.c_int, []),
     "ps_prof_get": (C.c_int, [C.c_char_p, c_dp, c_i64p, c_dp]),
@@ -368,6 +369,10 @@ class CApi:
     def set_sweep_min(self, n):
         """forward-only batches of at least n alignments run one wavefront per alignment (negative: the default)"""
         self.check(self.lib.ps_set_sweep_min(int(n)))
+
+    def set_sweep2_min(self, n):
+        """Alignment::update batches (forward + backward sweep per alignment) of at least n sweeps run one wavefront per sweep"""
+        self.check(self.lib.ps_set_sweep2_min(int(n)))
 
     def prof_enable(self, on):
         self.check(self.lib.ps_prof_enable(int(on)))   # 1: synchronous per launch, 2: event pairs queued and read by prof_get

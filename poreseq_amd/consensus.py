@@ -85,6 +85,8 @@ def consensus_regions(pas, params=None, reps=4, refseqs=None, logs=None, batch=N
             out[i] = (refseqs[i], 100)
         else:
             todo.append(i)
+    if not todo and batch is not None:
+        batch.close()                               # (every region had fewer than five events: nothing ran, the handles still go)
     if todo:
         def note(i, call, nb):
             if logs is not None:

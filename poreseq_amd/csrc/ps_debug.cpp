@@ -23,11 +23,18 @@ int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* sta
     PS_HIP(hipMemcpyAsync(&o, a->d_out + ev, sizeof(o), hipMemcpyDeviceToHost, rt->stream));
     std::vector<int> lb(J.lbn);
     PS_HIP(hipMemcpyAsync(lb.data(), b.d.lb + J.lb_off, J.lbn * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
-    std::vector<double2> rec((size_t)J.S * P);
-    std::vector<unsigned short> flg((size_t)J.S * P);
+    // skewed matrices of k_fill (REC[i + j][i mod P], u16 step words) or strip matrices of k_sweep2 (REC[j + q][r][q mod 64], one code byte per cell)
+    const int K = J.K;
+    const SweepJob sj0 = K ? b.sjobs[0] : SweepJob();
+    const size_t ncell = K ? (size_t)sj0.T * 64 * K : (size_t)J.S * P;
+    std::vector<double2> rec(ncell);
+    std::vector<unsigned short> flg(K ? 0 : ncell);
+    std::vector<unsigned char> codes(K ? ncell : 0);
     PS_HIP(hipMemcpyAsync(rec.data(), b.d.rec + J.mat_off[dir], rec.size() * sizeof(double2), hipMemcpyDeviceToHost, rt->stream));
-    PS_HIP(hipMemcpyAsync(flg.data(), b.d.flg + J.mat_off[dir], flg.size() * sizeof(unsigned short), hipMemcpyDeviceToHost, rt->stream));
+    if (!K) PS_HIP(hipMemcpyAsync(flg.data(), b.d.flg + J.mat_off[dir], flg.size() * sizeof(unsigned short), hipMemcpyDeviceToHost, rt->stream));
+    else PS_HIP(hipMemcpyAsync(codes.data(), b.sd.codes + sj0.codes_off, codes.size(), hipMemcpyDeviceToHost, rt->stream));
     PS_HIP(hipStreamSynchronize(rt->stream));
+    auto plane_sz = [](int rem) { return rem >= 16 ? 16 : rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1; };
     // column 0 is the blank column: rows 0..n0, all zero (cpp/Alignment.cpp:42-43)
     for (int i = 0; i <= n0; i++) { main[(size_t)i * ld] = 0.0; if (stay) stay[(size_t)i * ld] = 0.0; }
     if (o.inert) return PS_OK;
@@ -38,8 +45,22 @@ int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* sta
         ce = std::min(std::max(ce, 1), n0);
         const int i0 = std::max(1, ce - J.W), i1 = std::min(n0, ce + J.W);
         for (int i = i0; i <= i1; i++) {
-            const size_t at = (size_t)(i + c) * P + (i % P);
             const size_t to = (size_t)i * ld + c;
+            if (K) {
+                const int q = (i - 1) / K, r = (i - 1) % K;
+                const size_t at = ((size_t)(c + q) * K + r) * 64 + (q & 63);
+                main[to] = rec[at].x;
+                if (stay) stay[to] = rec[at].y;
+                if (dir == 0 && (sm || ss)) {
+                    int r0 = 0, off = 0;
+                    for (;;) { const int sz = plane_sz(K - r0); if (r < r0 + sz) { off = 64 * r0 + (q & 63) * sz + (r - r0); break; } r0 += sz; }
+                    const unsigned by = codes[(size_t)(c + q) * 64 * K + off];
+                    if (sm) sm[to] = (uint8_t)((by & 7) == 7 ? 255 : (by & 7));
+                    if (ss) ss[to] = (uint8_t)(((by >> 3) & 3) ? 3 + ((by >> 3) & 3) : 0);
+                }
+                continue;
+            }
+            const size_t at = (size_t)(i + c) * P + (i % P);
             main[to] = rec[at].x;
             if (stay) stay[to] = rec[at].y;
             // back-pointer codes exist for the forward matrix only (nothing reads the backward ones)

@@ -35,6 +35,16 @@ __device__ __forceinline__ void band_of(const int* __restrict__ lb, int dir, int
 }
 
 
+// index of cell (row i, column j) of a job's forward (dir 0) / backward (dir 1) matrix in the record pool: skewed storage
+// REC[i + j][i mod P] (k_fill), or strip storage REC[j + q][r][q mod 64] with q = (i - 1) / K, r = (i - 1) mod K (k_sweep2)
+__device__ __forceinline__ int64_t rec_index(const JobD& J, int dir, int i, int j) {
+    if (J.K) {
+        const int q = (i - 1) / J.K, r = (i - 1) - q * J.K;
+        return J.mat_off[dir] + ((int64_t)(j + q) * J.K + r) * 64 + (q & 63);
+    }
+    return J.mat_off[dir] + (int64_t)(i + j) * J.P + i % J.P;
+}
+
 __device__ __forceinline__ double wave_shr1(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);

@@ -486,7 +486,24 @@ int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::
         regs[r].rng = rngs[r]; regs[r].draw = vit_draw;
     }
     std::vector<std::vector<std::vector<int>>> paths;
-    PS_TRY(viterbi_device_multi(rt, regs, nkeep, skip, stay, mmin, mmax, &paths));
+    {
+        // sub-batches of regions that fit a quarter of this runtime's device share (obs, trimmed means, back-pointers and forward
+        // probabilities: 26 KB per position; ~270 MB per 10 kb region); the regions' generators keep the results the same however
+        // the batch is cut; a sub-batch the device has no memory for is cut in two
+        auto need = [&](size_t k) { return 26.0 * 1024.0 * (double)regs[k].T + 32.0 * (double)regs[k].T * regs[k].E; };
+        double cap = std::max(1e9, device_share_bytes() / 4);
+        for (size_t k0 = 0; k0 < regs.size();) {
+            size_t k1 = k0;
+            double acc = 0;
+            for (; k1 < regs.size(); k1++) { const double add = need(k1); if (k1 > k0 && acc + add > cap) break; acc += add; }
+            std::vector<std::vector<std::vector<int>>> part;
+            const int rc = viterbi_device_multi(rt, std::vector<VitRegionH>(regs.begin() + k0, regs.begin() + k1), nkeep, skip, stay, mmin, mmax, &part);
+            if (rc == PS_ERR_NOMEM && k1 - k0 > 1) { cap *= 0.5; continue; }   // (nothing of this sub-batch has been drawn yet: allocation comes first)
+            PS_TRY(rc);
+            for (auto& pr : part) paths.push_back(std::move(pr));
+            k0 = k1;
+        }
+    }
     tk.lap("device");
     par_for(R, [&](int r) { for (auto& p : paths[r]) outs[r]->push_back(path_to_bases(p)); });
     tk.lap("paths to bases");

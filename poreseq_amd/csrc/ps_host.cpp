@@ -165,7 +165,16 @@ int second_stream(Runtime* rt, hipStream_t* out) {
     // 4 batches x 2 streams 69 kb/s; the overlap a second stream buys comes from the other batches anyway.
     // (PORESEQ_ONE_STREAM forces it for a lone thread too; read once: getenv races with setenv from other threads.)
     static const bool one = getenv("PORESEQ_ONE_STREAM") != nullptr;
-    if (one || live_runtimes() > 1) { *out = rt->stream; return PS_OK; }
+    // PORESEQ_FORCE_STREAM2 (diagnostics only, tests/test_hip_variant.py and DESIGN.md section 9): second streams even with
+    // several threads inside the library; "prio" puts them on the next stream priority level, as round 2's experiment did
+    static const char* force = getenv("PORESEQ_FORCE_STREAM2");
+    if (!force && (one || live_runtimes() > 1)) { *out = rt->stream; return PS_OK; }
+    if (!rt->stream2 && force && !strcmp(force, "prio")) {
+        static std::atomic<int> seq(1);
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo > hi)
+            PS_HIP(hipStreamCreateWithPriority(&rt->stream2, hipStreamNonBlocking, hi + seq++ % (lo - hi + 1)));
+    }
     if (!rt->stream2) PS_HIP(hipStreamCreateWithFlags(&rt->stream2, hipStreamNonBlocking));
     *out = rt->stream2;
     return PS_OK;
@@ -380,6 +389,7 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
     d.njobs = (int)jobs.size();
     d.lb = rt->buf("lb").as<int>(); d.lo = rt->buf("lo").as<int>(); d.hi = rt->buf("hi").as<int>();
     d.rec = nullptr; d.flg = nullptr;
+    d.s_sj = nullptr; d.s_band = nullptr; d.s_qlo = nullptr; d.s_qhi = nullptr;
     d.cmax = rt->buf("cmax").as<double>(); d.pm = rt->buf("pm").as<double>();
     d.maxw = rt->buf("maxw").as<int>();
     d.log2pi = std::log(2 * M_PI);  // cpp/AlignUtil.h:24
@@ -396,8 +406,13 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
 // footprint (guess_slots) and split when realign() finds the matrices 20 % over the share, or the device short of memory.
 double device_share_bytes() {
     if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
-    size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 48e9;
+    static std::atomic<size_t> dev_total(0);       // the device's memory size does not change: asked once
+    size_t tot = dev_total.load();
+    if (!tot) {
+        size_t fr = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 48e9;
+        dev_total.store(tot);
+    }
     return std::max(2e9, 0.65 * (double)tot / std::max(4, peak_runtimes()));
 }
 
@@ -592,8 +607,10 @@ int Align::refs_to_host(Runtime* rt) {
 // forward fill + backtrace + updaterefs of a batch (the body of ScoreAlignments per event,
 // cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
 static int sweep_min_default() { static const int v = getenv("PORESEQ_SWEEP_MIN") ? atoi(getenv("PORESEQ_SWEEP_MIN")) : 400; return v; }
-static std::atomic<int> g_sweep_min(-1);
+static int sweep2_min_default() { static const int v = getenv("PORESEQ_SWEEP2_MIN") ? atoi(getenv("PORESEQ_SWEEP2_MIN")) : (1 << 30); return v; }
+static std::atomic<int> g_sweep_min(-1), g_sweep2_min(-1);
 void sweep_min_set(int n) { g_sweep_min.store(n); }
+void sweep2_min_set(int n) { g_sweep2_min.store(n); }
 bool sweep_enabled() { static const bool off = getenv("PORESEQ_NO_SWEEP") != nullptr; return !off; }
 
 // device bytes one forward-only job of AlignData a (n0 levels against C states) will probably take: step codes of a strip sweep,
@@ -606,8 +623,9 @@ double fwd_job_bytes(const Align* a, int n0, int C) {
     return ((double)n0 + C + 1 + MAT_FRONT + MAT_BACK) * guess_slots(a) * 18.0;
 }
 
-// Forward-only batches (ScoreAlignments): one wave per alignment, one byte per cell (ps_sweep.hip).  Returns -1 when the batch
-// has to take the k_fill path instead (band too wide for 64 strips of any supported height).
+// Strip sweeps (ps_sweep.hip): one wave per alignment and direction.  Forward-only batches (ScoreAlignments) keep one byte per
+// cell; Alignment::update batches (ndir == 2, ScoreMutations) also the {main, stay} records of both directions, in strip order.
+// Returns -1 when the batch has to take the k_fill path instead (band too wide for 64 strips of any supported height).
 static int realign_sweep(Runtime* rt, Batch& b, double cap) {
     int W = 0;
     for (const JobD& j : b.jobs) W = std::max(W, j.W);
@@ -621,25 +639,35 @@ static int realign_sweep(Runtime* rt, Batch& b, double cap) {
         int* w = nullptr;
         PS_TRY(rt->down(&w, b.sd.maxwin, (size_t)1));
         PS_HIP(hipStreamSynchronize(rt->stream));
-        { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign (strip sweep): %d jobs, K = %d, widest window %d strips\n", b.d.njobs, K, *w); }
+        { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign (strip sweep): %d jobs x %d, K = %d, widest window %d strips\n", b.d.njobs, b.ndir, K, *w); }
         if (*w <= sweep_win_max()) break;
         K = sweep_next_k(K);
-        if (!K) return -1;
+        if (!K) { for (JobD& j : b.jobs) j.K = 0; return -1; }
     }
-    if (cap > 0 && (double)b.sweep_code_bytes > cap) {
+    const double bytes = (double)b.sweep_code_bytes + 16.0 * (double)b.sweep_recs;
+    if (cap > 0 && bytes > cap) {
         static const bool trace = getenv("PORESEQ_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[ps] realign (strip sweep): %.2f GB of step codes at K = %d, over the share: split\n", b.sweep_code_bytes * 1e-9, K);
+        if (trace) fprintf(stderr, "[ps] realign (strip sweep): %.2f GB of step codes%s at K = %d, over the share: split\n", bytes * 1e-9, b.ndir == 2 ? " and records" : "", K);
         b.P = 0;
         return PS_SPLIT;
     }
     {
-        // the step codes live in the pool of the score matrices (a runtime runs one batch at a time: never both)
-        const int rc = ensure_matrix_pools(rt, (size_t)std::max<int64_t>(b.sweep_code_bytes, 1), 0, cap > 0);
+        // forward-only: the step codes live in the pool of the score matrices (a runtime runs one batch at a time: never both);
+        // with both directions the records take that pool and the codes the step words'
+        const size_t need_rec = b.ndir == 2 ? (size_t)std::max<int64_t>(b.sweep_recs, 1) * sizeof(double2) : (size_t)std::max<int64_t>(b.sweep_code_bytes, 1);
+        const size_t need_flg = b.ndir == 2 ? (size_t)std::max<int64_t>(b.sweep_code_bytes, 1) : 0;
+        const int rc = ensure_matrix_pools(rt, need_rec, need_flg, cap > 0);
         if (rc == PS_ERR_NOMEM && cap > 0) { b.P = 0; return PS_SPLIT; }
         PS_TRY(rc);
-        b.sd.codes = rt->buf("rec").as<unsigned char>();
+        b.sd.codes = b.ndir == 2 ? rt->buf("flg").as<unsigned char>() : rt->buf("rec").as<unsigned char>();
+        if (b.ndir == 2) {
+            b.d.rec = rt->buf("rec").as<double2>(); b.d.flg = nullptr;
+            b.d.s_sj = b.sd.sj; b.d.s_band = b.sd.band; b.d.s_qlo = b.sd.qlo; b.d.s_qhi = b.sd.qhi;
+            PS_TRY(rt->up(rt->buf("jobs").p, b.jobs.data(), b.jobs.size() * sizeof(JobD)));   // JobD.K, JobD.mat_off
+            PS_HIP(hipMemsetAsync(b.d.cmax, 0, b.ncols * sizeof(double), rt->stream));
+        }
     }
-    if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs; }
+    if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs * b.ndir; }
     PS_TRY(sweep_run(rt, b));
     PS_TRY(launch_updaterefs(rt, b.d));
     return PS_OK;
@@ -650,8 +678,9 @@ int realign(Runtime* rt, Batch& b, double cap) {
     // forward-only batches take the strip sweep (one wave per alignment) from ps_set_sweep_min / PORESEQ_SWEEP_MIN alignments on
     // (default 400); a smaller batch alone on the chip finishes sooner with a workgroup per alignment (k_fill: ~11 ms against
     // ~25 ms for a 10 kb sweep; with several batches in flight the two take the same time)
-    const int sweep_min = g_sweep_min.load() >= 0 ? g_sweep_min.load() : sweep_min_default();
-    if (b.ndir == 1 && sweep_enabled() && b.d.njobs >= sweep_min) {
+    const int sweep_min = b.ndir == 1 ? (g_sweep_min.load() >= 0 ? g_sweep_min.load() : sweep_min_default())
+                                      : (g_sweep2_min.load() >= 0 ? g_sweep2_min.load() : sweep2_min_default());
+    if (sweep_enabled() && b.d.njobs * b.ndir >= sweep_min) {
         const int rc = realign_sweep(rt, b, cap);
         if (rc != -1) return rc;
     }
@@ -697,7 +726,10 @@ int realign(Runtime* rt, Batch& b, double cap) {
 // run fn(k) for k in [0, n) on up to 32 host threads (disjoint outputs; the GPU work of a batched call is enqueued by the caller)
 void par_for(int n, const std::function<void(int)>& fn) {
     if (n <= 1) { if (n == 1) fn(0); return; }
-    const int nth = std::min(n, 32);
+    // helper threads per call: PORESEQ_HOST_THREADS (poreseq_amd.dist.init sets it to this rank's share of the node's cores when
+    // several ranks share a node), else up to 32
+    static const int cap = [] { const char* e = getenv("PORESEQ_HOST_THREADS"); const int v = e ? atoi(e) : 32; return std::max(1, std::min(v, 64)); }();
+    const int nth = std::min(n, cap);
     std::atomic<int> next(0);
     auto work = [&] { for (int k = next++; k < n; k = next++) fn(k); };
     std::vector<std::thread> th;

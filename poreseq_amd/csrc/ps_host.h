@@ -45,7 +45,7 @@ struct Batch {
     std::vector<SweepJob> sjobs;
     SweepD sd;
     int sweep_K = 0, sweep_maxT = 0;
-    int64_t sweep_code_bytes = 0, sweep_sb = 0;
+    int64_t sweep_code_bytes = 0, sweep_sb = 0, sweep_recs = 0;
     int build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir, int lb_extra);
     int place(Runtime* rt, int P, bool can_split = false);
     double fill_alg_bytes() const;
@@ -91,10 +91,11 @@ void accumulate_likes(const double* ra, const double* rl, int n, int C, double* 
 int sweep_guess_k(int W);                         // strip height to try first for realign_width W (0: too wide for a strip sweep)
 int sweep_next_k(int K);                          // next larger one (0: none)
 int sweep_win_max();                              // widest window of strips a sweep supports
-double sweep_job_bytes(int n0, int C, int K);     // bytes of step codes of one job
+double sweep_job_bytes(int n0, int C, int K, bool full = false);   // bytes of one job: step codes (+ both directions' records)
 int sweep_prepare(Runtime* rt, Batch& b, int K);  // band / qlo tables + the widest window (b.sd.maxwin, device)
 int sweep_run(Runtime* rt, Batch& b);             // sweeps, maxima, backtrace, path scores (b.sd.codes placed by the caller)
 void sweep_min_set(int n);                        // forward-only batches of at least n alignments take the strip sweep (< 0: default)
+void sweep2_min_set(int n);                       // the same for Alignment::update batches (sweeps = 2 per alignment)
 bool sweep_enabled();                             // PORESEQ_NO_SWEEP unset
 double fwd_job_bytes(const Align* a, int n0, int C);   // device bytes one forward-only alignment job will probably take
 

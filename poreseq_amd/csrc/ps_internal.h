@@ -129,7 +129,8 @@ struct JobD {
     int force_inert; // realign_width == 0: every Alignment is a no-op (cpp/Alignment.cpp:85-86)
     int P;           // slots per anti-diagonal (multiple of 64, >= widest footprint + 9; k_fill_wide: multiple of 128, >= footprint + 2)
     int lbn;         // entries in each lb table (C + 2 + extra)
-    int pad0, pad1;
+    int K;           // 0: skewed matrices (k_fill); > 0: strip matrices of K rows per lane (k_sweep2): REC[step][row of the strip][lane]
+    int pad1;
     int64_t lb_off;      // lb table the fills were made with          (int32[lbn])
     int64_t lbn_off;     // lb table after the latest backtrace        (int32[lbn])
     int64_t mat_off[2];  // record offset of anti-diagonal 0 of the forward / backward matrix
@@ -157,6 +158,7 @@ constexpr int MAT_FRONT = 8;   // spare anti-diagonals in front of every matrix 
 constexpr int MAT_BACK = 16;   // and behind it (the last loop body runs past S)
 constexpr int LO_PAD = 160;    // LO / HI entries behind S, all -1 (k_fill prefetches them in chunks of 64)
 
+struct SweepJob;
 // device pointers of the pools a batch of jobs lives in (filled by Batch::build / place)
 struct BatchD {
     const JobD* jobs;
@@ -171,6 +173,11 @@ struct BatchD {
     int* maxw;                            // widest band footprint of any job of the batch on one anti-diagonal (sizes P)
     int fastdiv;                          // every AlignData of the batch allows k_fill's tabulated reciprocals
     double log2pi;
+    // strip matrices (JobD.K > 0, k_sweep2): the sweep jobs (2 per job: forward, backward) and their band / qlo / qhi tables
+    const SweepJob* s_sj;
+    const int2* s_band;
+    const int* s_qlo;
+    const int* s_qhi;
 };
 
 // ---- strip sweeps (ps_sweep.hip): forward-only alignments, one wave per job ------------------------
@@ -187,10 +194,12 @@ struct SweepD {
     const SweepJob* sj;
     int2* band;
     int* qlo;
+    int* qhi;               // lowest / highest strip in band per step (-1: none)
     unsigned char* codes;   // one byte per cell: main step (3 bits, 7 = implicit) | stay step << 3 | main <= 0 << 5 | stay <= 0 << 6
     StripBest* sb;
     int* maxwin;            // widest window of strips in band on one step, over the batch
     int K;
+    int ndir;               // 1: forward-only jobs; 2: sweep job jd = 2 * job + direction
 };
 
 // ---- kernel launchers (ps_kernels.hip) ------------------------------------------------------
@@ -199,6 +208,7 @@ int launch_lb(Runtime* rt, const BatchD& b, int which /*0: lb_off, 1: lbn_off*/,
 int launch_lo(Runtime* rt, const BatchD& b, int ndir, int64_t maxS);
 int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int ndir, int64_t maxS, int P, int64_t ncols);
 int launch_backtrace(Runtime* rt, const BatchD& b, int maxn);
+int launch_prefix(Runtime* rt, const BatchD& b, int ndir);
 
 struct ScoreArgs {
     int job0, njobs;           // the AlignData's jobs inside the batch

@@ -25,6 +25,7 @@
 //                 k_lb for the new band centres
 //   k_old / k_score / k_reduce   edit scoring (scoreMutation + columnMax) and the per-edit sums
 #include <algorithm>
+#include <atomic>
 
 #include "ps_internal.h"
 #include "ps_slowmask.h"
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
         if (c <= J.C) pm[c] = v;
         carry = __shfl(v, 63);
     }
-    if (dir == 0) {
+    if (dir == 0 && J.K == 0) {   // (strip sweeps hand in their best cell themselves: k_best)
         const double best = carry;
         int bj = 0x7fffffff;
         if (best > 0.0)
@@ -803,23 +804,21 @@ __global__ __launch_bounds__(256) void k_fill_like(BatchD b) {
 // Only rows where both columns are in band can exceed the two running maxima (stay <= main <= max).
 // ------------------------------------------------------------------------------------------------
 __device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, int lane, int nl) {
-    const int C = J.C, n0 = J.n0, P = J.P;
+    const int C = J.C, n0 = J.n0;
     if ((unsigned)raf >= (unsigned)(C + 1)) raf = C;
     if ((unsigned)rab >= (unsigned)(C + 1)) rab = C;
     const int* lb = b.lb + J.lb_off;
     int f0 = 0, f1 = n0, b0 = 0, b1 = n0;
     if (raf > 0) band_of(lb, 0, raf, C, n0, J.W, f0, f1);
     if (rab > 0) band_of(lb, 1, rab, C, n0, J.W, b0, b1);
-    const double2* __restrict__ rf = b.rec + J.mat_off[0];
-    const double2* __restrict__ rb = b.rec + J.mat_off[1];
     // jb = n0 - jf + 1 in [b0, b1]  <=>  jf in [n0 + 1 - b1, n0 + 1 - b0]
     const int lo = max(max(1, f0), n0 + 1 - b1), hi = min(min(n0, f1), n0 + 1 - b0);
     double sm = 0.0;
     for (int jf = lo + lane; jf <= hi; jf += nl) {
         const int jb = n0 - jf + 1;
         double2 fv = make_double2(0.0, 0.0), bv = make_double2(0.0, 0.0);
-        if (raf > 0) fv = rf[(int64_t)(jf + raf) * P + slot_of(jf, P)];
-        if (rab > 0) bv = rb[(int64_t)(jb + rab) * P + slot_of(jb, P)];
+        if (raf > 0) fv = b.rec[rec_index(J, 0, jf, raf)];
+        if (rab > 0) bv = b.rec[rec_index(J, 1, jb, rab)];
         sm = fmax(sm, fmax(fv.x + bv.x, fv.y + bv.y));
     }
     for (int off = 1; off < nl; off <<= 1) sm = fmax(sm, __shfl_xor(sm, off));
@@ -855,7 +854,7 @@ __global__ __launch_bounds__(256) void k_oldall(BatchD b, const ScoreArgs* __res
     const ScoreArgs& a = A[blockIdx.z];
     if (!a.oldall || !a.nr0 || (int)blockIdx.y >= a.njobs) return;
     const JobD& J = b.jobs[a.job0 + blockIdx.y];
-    if (J.out->inert) return;
+    if (J.out->inert || J.K) return;
     const int s0 = blockIdx.x * OA_SB;
     const int S = (int)J.S, P = J.P, n0 = J.n0, C = J.C;
     if (s0 >= S) return;
@@ -919,6 +918,76 @@ __global__ __launch_bounds__(256) void k_oldall(BatchD b, const ScoreArgs* __res
     }
 }
 
+// The same pass over strip matrices (k_sweep2): the forward records of one step t and strip row r are 64 consecutive records
+// (one per lane = strip); their partners in the backward matrix are 64 consecutive records too, in reverse order (row n0 - i + 1 of
+// backward column C - j + 1: strip and step move by one per lane in opposite senses).  grid (ceil(maxT / OA_ST), njobs, regions), block 256.
+constexpr int OA_ST = 16;      // steps per block
+__global__ __launch_bounds__(256) void k_oldall_s(BatchD b, const ScoreArgs* __restrict__ A) {
+    __shared__ unsigned long long s_max[OA_COLS];
+    __shared__ int s_jbase, s_ok;
+    const ScoreArgs& a = A[blockIdx.z];
+    if (!a.oldall || !a.nr0 || (int)blockIdx.y >= a.njobs) return;
+    const int job = a.job0 + blockIdx.y;
+    const JobD& J = b.jobs[job];
+    if (J.out->inert || !J.K) return;
+    const SweepJob& SF = b.s_sj[2 * job];
+    const SweepJob& SB = b.s_sj[2 * job + 1];
+    const int K = J.K, T = SF.T, n0 = J.n0, C = J.C;
+    const int t0 = blockIdx.x * OA_ST;
+    if (t0 >= T) return;
+    const int nst = min(OA_ST, T - t0);
+    const int* __restrict__ QL = b.s_qlo + SF.q_off;
+    const int* __restrict__ QH = b.s_qhi + SF.q_off;
+    const int2* __restrict__ bandF = b.s_band + SF.band_off;
+    const int2* __restrict__ bandB = b.s_band + SB.band_off;
+    if (threadIdx.x == 0) {
+        int jmin = 0x7fffffff, jmax = -1;
+        for (int k = 0; k < nst; k++) {
+            const int ql = QL[t0 + k];
+            if (ql < 0) continue;
+            jmax = max(jmax, t0 + k - ql);
+            jmin = min(jmin, t0 + k - QH[t0 + k]);
+        }
+        s_jbase = jmin;
+        s_ok = jmax < 0 ? -1 : (jmax - jmin + 1 <= OA_COLS ? 1 : 0);
+    }
+    for (int k = threadIdx.x; k < OA_COLS; k += 256) s_max[k] = 0ull;
+    __syncthreads();
+    if (s_ok < 0) return;
+    const bool use_lds = s_ok == 1;
+    const int jbase = s_jbase;
+    const double2* __restrict__ rf = b.rec + J.mat_off[0];
+    unsigned long long* gmax = (unsigned long long*)(a.oldall + (size_t)blockIdx.y * a.oldall_pitch);
+    const int lane = threadIdx.x & 63;
+    for (int p = threadIdx.x >> 6; p < nst * K; p += 4) {
+        const int t = t0 + p / K, r = p % K;
+        const int ql = __builtin_amdgcn_readfirstlane(QL[t]);
+        if (ql < 0) continue;
+        const int q = ql + ((lane - ql) & 63);
+        const int i = q * K + 1 + r, j = t - q;
+        if (j < 1 || j > C || i > n0) continue;
+        const int2 bf = bandF[j];
+        if (i < bf.x || i > bf.y) continue;
+        const int ib = n0 - i + 1, cb = C - j + 1;                      // partner cell in backward coordinates
+        const int2 bb = bandB[cb];
+        if (ib < bb.x || ib > bb.y) continue;                           // partner outside the backward band
+        const double2 fv = rf[((int64_t)t * K + r) * 64 + lane];
+        const double2 bv = b.rec[rec_index(J, 1, ib, cb)];
+        const double v = fmax(fv.x + bv.x, fv.y + bv.y);
+        if (v > 0.0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            if (use_lds) atomicMax(&s_max[j - jbase], bits); else atomicMax(&gmax[j], bits);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < OA_COLS; q += 256) {
+            const unsigned long long v = s_max[q];
+            if (v) atomicMax(&gmax[jbase + q], v);
+        }
+    }
+}
+
 // old[r0] = max(0, column sums, forward MaxInfo up to r0, backward MaxInfo up to C - r0 + 1)  (cpp/Alignment.h:181-214); grid (ceil(nr0/256), njobs)
 __global__ __launch_bounds__(256) void k_oldfin(BatchD b, const ScoreArgs* __restrict__ A) {
     const ScoreArgs& a = A[blockIdx.z];
@@ -959,7 +1028,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const int it = (blockIdx.x * 4 + wave) * IPW + g;
     const bool have = it < nitems;
     const int m = have ? items[it] : 0;
-    const int n0 = J.n0, C = J.C, P = J.P, WS = a.ws;
+    const int n0 = J.n0, C = J.C, WS = a.ws;
     const bool live = have && !J.out->inert && !a.m_skip[m];
     if (__ballot(live) == 0ull) {
         if (have && c == 0) a.delta[(size_t)job * a.nitems_per_job + m] = 0.0;
@@ -974,8 +1043,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const int* __restrict__ lbf = b.lb + J.lb_off;    // tables the fills were made with
     const int* __restrict__ lbn = b.lb + J.lbn_off;   // after the backtrace: centres of the new columns
     const double4* __restrict__ levf = (const double4*)J.lev[0];
-    const double2* __restrict__ rf = b.rec + J.mat_off[0];
-    const double2* __restrict__ rb = b.rec + J.mat_off[1];
     const double lsk = J.lsk, lst = J.lst, lex = J.lex, lin = J.lin;
 
     // band of the back column the target is combined with
@@ -1027,7 +1094,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 L = 0.0;
                 if (mine && i >= p0 && i <= p1 && i >= 1) {
                     if (ch > 0) L = carry[i - p0];
-                    else if (sidx > 0) L = rf[(int64_t)(i + sidx) * P + slot_of(i, P)].x;
+                    else if (sidx > 0) L = b.rec[rec_index(J, 0, i, sidx)].x;
                 }
             }
             const double D = lprev;
@@ -1059,7 +1126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     const int jb = n0 - i + 1;
                     if (jb >= bb0 && jb <= bb1) {
                         double2 bv = make_double2(0.0, 0.0);
-                        if (backind > 0) bv = rb[(int64_t)(jb + backind) * P + slot_of(jb, P)];
+                        if (backind > 0) bv = b.rec[rec_index(J, 1, jb, backind)];
                         tm = fmax(tm, fmax(nm + bv.x, ns + bv.y));
                     }
                 }
@@ -1164,23 +1231,23 @@ static void fill_launch(Runtime* rt, const BatchD& b, const int* d_pairs, int nw
 
 int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int ndir, int64_t maxS, int P, int64_t ncols) {
     if (!b.njobs) return PS_OK;
-    static bool attr_set = false;   // more than the default 64 KB of dynamic LDS needs the attribute (idempotent; racing threads set the same value)
-    if (!attr_set) {
+    static std::atomic<bool> attr_set(false);   // more than the default 64 KB of dynamic LDS needs the attribute (idempotent: racing threads set the same value)
+    if (!attr_set.load(std::memory_order_acquire)) {
 #define PS_FILL_ATTR(...) PS_HIP(hipFuncSetAttribute((const void*)k_fill<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
         PS_FILL_ATTR(768, true, true, false); PS_FILL_ATTR(768, true, false, false);
         PS_FILL_ATTR(512, false, true, false); PS_FILL_ATTR(512, false, false, false);
         PS_FILL_ATTR(512, false, true, true); PS_FILL_ATTR(512, false, false, true);
         PS_FILL_ATTR(1024, false, true, false); PS_FILL_ATTR(1024, false, false, false);
 #undef PS_FILL_ATTR
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     PS_HIP(hipMemsetAsync(b.cmax, 0, ncols * sizeof(double), rt->stream));
     if (P > 1024) {   // footprint wider than one lane per row: the two-slots-per-thread sweep
-        static bool wide_attr = false;
-        if (!wide_attr) {
+        static std::atomic<bool> wide_attr(false);
+        if (!wide_attr.load(std::memory_order_acquire)) {
             PS_HIP(hipFuncSetAttribute((const void*)k_fill_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             PS_HIP(hipFuncSetAttribute((const void*)k_fill_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            wide_attr = true;
+            wide_attr.store(true, std::memory_order_release);
         }
         const int rc = 4096;
         const size_t lds = (size_t)2 * P * 24 + (size_t)rc * 8;
@@ -1197,7 +1264,9 @@ int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int
     // forward-only jobs of one event (candidate sequences of FindMutations), longest with longest
     // (a launch that fits the chip with one sweep per workgroup keeps them apart: a lone sweep finishes ~20 % sooner than a pair,
     //  and a launch this small is on some region's critical path)
-    const char* pm_env = getenv("PORESEQ_DEBUG_PAIR_MIN");   // (tests and tuning probes: read at every launch)
+    // (a test hook that tests/test_hip_parity.py changes between calls of one process: read per launch; nothing in the library or
+    //  its drivers calls setenv, so the read does not race)
+    const char* pm_env = getenv("PORESEQ_DEBUG_PAIR_MIN");
     const int pair_min = pm_env ? atoi(pm_env) : PAIR_MIN_SWEEPS;
     bool pair = 2 * P <= 768 && b.njobs * ndir > pair_min;
     std::vector<int> pr;
@@ -1241,6 +1310,13 @@ int launch_fill(Runtime* rt, const BatchD& b, const std::vector<JobD>& jobs, int
     return PS_OK;
 }
 
+int launch_prefix(Runtime* rt, const BatchD& b, int ndir) {
+    if (!b.njobs) return PS_OK;
+    hipLaunchKernelGGL(k_prefix, dim3(b.njobs * ndir), dim3(64), 0, rt->stream, b, ndir);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
 int launch_backtrace(Runtime* rt, const BatchD& b, int maxn) {
     if (!b.njobs) return PS_OK;
     hipLaunchKernelGGL(k_backtrace, dim3(b.njobs), dim3(256), 0, rt->stream, b);
@@ -1277,7 +1353,8 @@ int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs* d_sas, const std
     if (any_all) {
         // a list that touches most columns (Refine, ScorePoints): one coalesced pass over both matrices serves every position
         // (the caller has zeroed the oldall arrays)
-        hipLaunchKernelGGL(k_oldall, dim3((unsigned)((maxS + OA_SB - 1) / OA_SB), maxE, R), dim3(256), 0, rt->stream, b, d_sas);
+        if (b.s_sj) hipLaunchKernelGGL(k_oldall_s, dim3((unsigned)((maxS + OA_ST - 1) / OA_ST), maxE, R), dim3(256), 0, rt->stream, b, d_sas);   // (maxS >= every T)
+        else hipLaunchKernelGGL(k_oldall, dim3((unsigned)((maxS + OA_SB - 1) / OA_SB), maxE, R), dim3(256), 0, rt->stream, b, d_sas);
         hipLaunchKernelGGL(k_oldfin, dim3((maxnr0_all + 255) / 256, maxE, R), dim3(256), 0, rt->stream, b, d_sas);
         PS_LAUNCH_CHECK();
     }

@@ -52,28 +52,30 @@ constexpr int WIN_MAX = 62;       // strips in band on one step: two lanes stay 
 // column C + 1 an empty sentinel.  grid (ceil((maxC + 2) / 256), njobs)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_band(BatchD b, SweepD sw) {
-    const JobD& J = b.jobs[blockIdx.y];
-    const SweepJob& SJ = sw.sj[blockIdx.y];
+    const int jd = blockIdx.y, dir = jd % sw.ndir;
+    const JobD& J = b.jobs[jd / sw.ndir];
+    const SweepJob& SJ = sw.sj[jd];
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j > J.C + 1) return;
     int i0 = 0, i1 = J.n0;
     if (j > J.C) { i0 = J.n0 + 1; i1 = J.n0; }
-    else if (j >= 1) band_of(b.lb + J.lb_off, 0, j, J.C, J.n0, J.W, i0, i1);
+    else if (j >= 1) band_of(b.lb + J.lb_off, dir, j, J.C, J.n0, J.W, i0, i1);
     sw.band[SJ.band_off + j] = make_int2(i0, i1);
 }
 
-// qlo[t] = lowest strip in band on step t (-1: none) and the widest window of the batch (sw.maxwin).
+// qlo[t] / qhi[t] = lowest / highest strip in band on step t (-1: none) and the widest window of the batch (sw.maxwin).
 // Strip q works on column t - q; it is in band iff  i0(t-q) <= qK + K  (true from some q on: i0 falls as the column does)
-// and  i1(t-q) >= qK + 1  (true up to some q).  grid (ceil((maxT + Q_PAD) / 256), njobs)
+// and  i1(t-q) >= qK + 1  (true up to some q).  grid (ceil((maxT + Q_PAD) / 256), njobs * ndir)
 __global__ __launch_bounds__(256) void k_qlo(BatchD b, SweepD sw) {
-    const JobD& J = b.jobs[blockIdx.y];
-    const SweepJob& SJ = sw.sj[blockIdx.y];
+    const int jd = blockIdx.y;
+    const JobD& J = b.jobs[jd / sw.ndir];
+    const SweepJob& SJ = sw.sj[jd];
     const int t = blockIdx.x * 256 + threadIdx.x;
     int win = 0;
     if (t < SJ.T + Q_PAD) {
         const int K = sw.K, C = J.C;
         const int2* __restrict__ band = sw.band + SJ.band_off;
-        int res = -1;
+        int res = -1, top = -1;
         const int qa = max(0, t - C), qb = min(SJ.Q - 1, t - 1);
         if (t < SJ.T && qa <= qb && !J.out->inert) {
             int lo = qa, hi = qb + 1;                     // smallest q in [qa, qb] with i0(t - q) <= qK + K  (hi = qb + 1: none)
@@ -82,10 +84,12 @@ __global__ __launch_bounds__(256) void k_qlo(BatchD b, SweepD sw) {
                 res = lo;
                 int l2 = lo, h2 = qb;                     // largest q with i1(t - q) >= qK + 1
                 while (l2 < h2) { const int mid = (l2 + h2 + 1) >> 1; if (band[t - mid].y >= mid * K + 1) l2 = mid; else h2 = mid - 1; }
+                top = l2;
                 win = l2 - lo + 1;
             }
         }
         sw.qlo[SJ.q_off + t] = res;
+        sw.qhi[SJ.q_off + t] = top;
     }
     for (int off = 32; off; off >>= 1) win = max(win, __shfl_xor(win, off));
     if ((threadIdx.x & 63) == 0 && win > 0) atomicMax(sw.maxwin, win);
@@ -101,21 +105,27 @@ __device__ __forceinline__ double wave_ror1(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int K, bool FD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 2 : 1, K <= 10 ? 2 : 1)))
-void k_sweep(BatchD b, SweepD sw) {
-    const JobD& J = b.jobs[blockIdx.x];
-    if (J.out->inert) return;
-    const SweepJob& SJ = sw.sj[blockIdx.x];
+// One sweep.  DIR 0 / 1: forward / backward fill (cpp/Alignment.cpp:111-274 / 280-444: the backward cell adds its emission when it
+// is LEFT, so what a lane hands down and keeps for the diagonal is {main, stay + emission, main + emission}).  FULL: the sweep of
+// an Alignment::update (ScoreMutations) — every cell's {main, stay} record goes to REC[step][row of the strip][lane] (one
+// coalesced 1 KB store per row and step) and the per-column maxima (MaxInfo, cpp/Alignment.cpp:158, 270) through a 256-column
+// LDS ring to cmax; without it (ScoreAlignments) only the forward step codes and the per-strip maxima leave the chip.
+constexpr int RING = 256;       // columns of the maxima ring: the window's 62 + the 64 steps between two flushes, rounded up
+
+template <int K, int DIR, bool FULL, bool FD>
+__device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, const JobD& J, const SweepJob& SJ, unsigned long long* ring) {
     const int lane = threadIdx.x;
     const int C = uni(J.C), T = uni(SJ.T), n0 = uni(J.n0);
     typedef const __attribute__((address_space(4))) int* kcip;   // constant address space + uniform index = scalar load
     kcip QLO = (kcip)uni_ptr(sw.qlo + SJ.q_off);
+    kcip QHI = (kcip)uni_ptr(sw.qhi + SJ.q_off);
     gcip band = (gcip)uni_ptr((const int*)(sw.band + SJ.band_off));
     gcip st = (gcip)uni_ptr(J.st);
     const PS_GLOBAL char* model = (const PS_GLOBAL char*)uni_ptr((const char*)J.model8);
-    const PS_GLOBAL v4d* levs = (const PS_GLOBAL v4d*)uni_ptr(J.lev[0]);
+    const PS_GLOBAL v4d* levs = (const PS_GLOBAL v4d*)uni_ptr(J.lev[DIR]);
     PS_GLOBAL unsigned char* codes = (PS_GLOBAL unsigned char*)uni_ptr(sw.codes + SJ.codes_off);
+    PS_GLOBAL char* rec = (PS_GLOBAL char*)uni_ptr((char*)(b.rec + J.mat_off[DIR]));
+    double* gcmax = uni_ptr(b.cmax + J.col_off[DIR]);
     StripBest* SB = sw.sb + SJ.sb_off;
     const double lsk = J.lsk, lst = J.lst, lex = J.lex, lin = J.lin, off = J.lik_offset, log2pi = b.log2pi;
     const double NINF = -__builtin_inf();
@@ -128,8 +138,13 @@ void k_sweep(BatchD b, SweepD sw) {
         Ahead a;
         a.bd = *(const PS_GLOBAL v4i_a4*)(band + 2 * (j - 1));
         typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));
-        const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (j - 2));   // (four ints of -1 in front of the list: column 0 reads as invalid)
-        a.sp = s2.x; a.sc = s2.y;
+        if (DIR == 0) {
+            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (j - 2));   // (ints of -1 around the list: column 0 reads as invalid)
+            a.sp = s2.x; a.sc = s2.y;
+        } else {                                                          // backward column j holds states[C - j]
+            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (C - j));
+            a.sc = s2.x; a.sp = s2.y;
+        }
         return a;
     };
     auto model_row = [&](int state, double (&m)[8]) {
@@ -141,13 +156,18 @@ void k_sweep(BatchD b, SweepD sw) {
     // ---- lane state
     double lev[K][4];        // level records of the lane's strip: {mean, stdv, 3 log stdv, 1 / stdv}
     double pm[K];            // main scores of the previous column on the strip's rows; -infinity: no cell there
+    double pe[DIR ? K : 1];  // backward: main + emission of the previous column
 #pragma unroll
-    for (int r = 0; r < K; r++) { pm[r] = NINF; lev[r][0] = 0.0; lev[r][1] = 1.0; lev[r][2] = 0.0; lev[r][3] = 1.0; }
+    for (int r = 0; r < K; r++) { pm[r] = NINF; if (DIR) pe[r] = NINF; lev[r][0] = 0.0; lev[r][1] = 1.0; lev[r][2] = 0.0; lev[r][3] = 1.0; }
     int qcur = -1;
-    double bot_m = NINF, bot_s = NINF;   // the lane's last cell of the step: what the lane one down reads as its upper neighbour
-    double dm = NINF;                    // upper neighbour's main of the previous column (read one step earlier)
+    double bot_m = NINF, bot_s = NINF, bot_e = NINF;   // the lane's last cell of the step: what the lane one down reads as its upper neighbour
+    double dm = NINF, de = NINF;                       // upper neighbour's main (backward: and main + emission) of the previous column
     double lbest = 0.0;                  // strictly greater wins: the first cell of the strip (column, then row) holding its maximum
     int lbt = 0, lbr = 0;
+    int flushed = 1, next_flush = 64;    // (FULL) columns below `flushed` have their maximum in memory
+    if (FULL) {
+        for (int k = lane; k < RING; k += 64) ring[k] = 0ull;
+    }
 
     int ql0 = QLO[1], ql1 = QLO[2];          // qlo of step t, t + 1 (scalar registers; T + Q_PAD entries, -1 behind T)
     Ahead a0 = fetch(1, ql0), a1 = fetch(2, ql1);
@@ -163,7 +183,7 @@ void k_sweep(BatchD b, SweepD sw) {
         const int j = t - q;
         if (live && q != qcur) {
             // the lane takes its next strip: hand in the old one's maximum, fetch the new level records
-            if (lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
+            if (DIR == 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
             lbest = 0.0;
             qcur = q;
 #pragma unroll
@@ -171,6 +191,7 @@ void k_sweep(BatchD b, SweepD sw) {
                 const v4d v = levs[min(q * K + r, n0 - 1)];
                 lev[r][0] = v.x; lev[r][1] = v.y; lev[r][2] = v.z; lev[r][3] = v.w;
                 pm[r] = NINF;
+                if (DIR) pe[r] = NINF;
             }
         }
         // emissions of the lane's K cells first: the model row is then free to receive the next column's (one step of lead)
@@ -188,11 +209,13 @@ void k_sweep(BatchD b, SweepD sw) {
             const int ra = valid ? a0.bd.z - base : K, rb = valid ? a0.bd.w - base : -1;   // band rows relative to the strip
             const int rc = a0.bd.x - base, rd_ = a0.bd.y - base;                          // previous column's band
             const bool pzero = a0.sp < 0;                            // previous column invalid (or column 0): its scores read as zero
-            double um = wave_ror1(bot_m), us = wave_ror1(bot_s);
-            double dprev = dm;
-            dm = um;
+            double um = wave_ror1(bot_m), us = wave_ror1(bot_s), ue = DIR ? wave_ror1(bot_e) : 0.0;
+            double dprev = dm, deprev = de;
+            dm = um; de = ue;
             const double lbefore = lbest;
-            unsigned cw[(K + 3) / 4];                                // the step's codes, four to a register
+            unsigned cw[(K + 3) / 4];                                // (forward) the step's codes, four to a register
+            double crun = 0.0;                                       // (FULL) the lane's share of its column's maximum
+            PS_GLOBAL char* recp = rec + ((size_t)t * K * 64 + lane) * 16;
 #pragma unroll
             for (int r = 0; r < K; r++) {
                 const double o = ov[r];
@@ -204,11 +227,11 @@ void k_sweep(BatchD b, SweepD sw) {
                 double L;
                 asm("v_max_f64 %0, %1, 0" : "=v"(L) : "v"(pmr));
                 const double D = rd ? dprev : 0.0;
-                const double cSTAY = um + o + lst;
-                const double cEXT = us + o + lex;
+                const double cSTAY = DIR == 0 ? um + o + lst : ue + lst;      // backward: (main + emission) of the cell above
+                const double cEXT = DIR == 0 ? us + o + lex : us + lex;       // backward: `us` carries stay + emission
                 const double cINS = um + lin;
                 const double cSKIP = L + lsk;
-                const double cMATCH = D + o;
+                const double cMATCH = DIR == 0 ? D + o : (rd ? deprev : 0.0);
                 const double cIGN = D + lin;
                 const double floor_s = top ? -BIG : 0.0;
                 const double t1 = fmax(floor_s, cSTAY);
@@ -218,33 +241,47 @@ void k_sweep(BatchD b, SweepD sw) {
                 nm = fmax(nm, cINS);
                 nm = fmax(nm, cIGN);
                 nm = fmax(nm, ns);
-                // step codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order (first candidate equal to the maximum)
-                unsigned ss = cSTAY > floor_s ? 1u : 0u;
-                ss = cEXT > t1 ? 2u : ss;
-                unsigned sm = 4u;
-                sm = cIGN == nm ? 3u : sm;
-                sm = cINS == nm ? 2u : sm;
-                sm = cMATCH == nm ? (vd ? 1u : 7u) : sm;
-                sm = cSKIP == nm ? 0u : sm;
-                sm = nm > 0.0 ? sm : 0u;
-                unsigned w = sm | (ss << 3) | (nm > 0.0 ? 0u : 32u) | (ns > 0.0 ? 0u : 64u);   // (every constant an inline operand)
-                w = act ? w : 96u;
-                asm volatile("" : "+v"(w));                          // keep the byte's shift out of the selects' constants (a VGPR per shifted literal otherwise)
-                if ((r & 3) == 0) cw[r >> 2] = w; else cw[r >> 2] |= w << (8 * (r & 3));
+                if (DIR == 0) {
+                    // step codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order (first candidate equal to the maximum)
+                    unsigned ss = cSTAY > floor_s ? 1u : 0u;
+                    ss = cEXT > t1 ? 2u : ss;
+                    unsigned sm = 4u;
+                    sm = cIGN == nm ? 3u : sm;
+                    sm = cINS == nm ? 2u : sm;
+                    sm = cMATCH == nm ? (vd ? 1u : 7u) : sm;
+                    sm = cSKIP == nm ? 0u : sm;
+                    sm = nm > 0.0 ? sm : 0u;
+                    unsigned w = sm | (ss << 3) | (nm > 0.0 ? 0u : 32u) | (ns > 0.0 ? 0u : 64u);   // (every constant an inline operand)
+                    w = act ? w : 96u;
+                    asm volatile("" : "+v"(w));                      // keep the byte's shift out of the selects' constants (a VGPR per shifted literal otherwise)
+                    if ((r & 3) == 0) cw[r >> 2] = w; else cw[r >> 2] |= w << (8 * (r & 3));
+                }
                 const double nmx = act ? nm : NINF, nsx = act ? ns : NINF;
                 dprev = pmr;
                 pm[r] = nmx;
-                um = nmx; us = nsx;
-                const bool gt = nmx > lbest;
-                lbest = gt ? nmx : lbest;
-                lbr = gt ? r : lbr;
+                if (DIR) { deprev = pe[r]; pe[r] = nmx + o; }
+                um = nmx;
+                us = DIR == 0 ? nsx : nsx + o;
+                if (DIR) ue = nmx + o;
+                if (FULL) {
+                    double rx;   // the stored record: the cell; zeros where there is none (the stay value of a top row is -1e300 and stays so)
+                    asm("v_max_f64 %0, %1, 0" : "=v"(rx) : "v"(nmx));
+                    *(PS_GLOBAL v2d*)(recp + (size_t)r * 1024) = (v2d){rx, act ? ns : 0.0};
+                    crun = fmax(crun, rx);
+                }
+                if (DIR == 0) {
+                    const bool gt = nmx > lbest;
+                    lbest = gt ? nmx : lbest;
+                    lbr = gt ? r : lbr;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            bot_m = um; bot_s = us;
-            lbt = lbest > lbefore ? t : lbt;
-            // ---- the step's codes: per row group one coalesced store
-            PS_GLOBAL unsigned char* dst = codes + (size_t)t * (64 * K);
-            {
+            bot_m = um; bot_s = us; bot_e = ue;
+            if (DIR == 0) lbt = lbest > lbefore ? t : lbt;
+            if (FULL) atomicMax(&ring[(unsigned)j & (RING - 1)], (unsigned long long)__double_as_longlong(crun));   // (scores >= 0 order like their bit patterns; 0 is a no-op)
+            if (DIR == 0) {
+                // ---- the step's codes: per row group one coalesced store
+                PS_GLOBAL unsigned char* dst = codes + (size_t)t * (64 * K);
                 int r0 = 0;
 #pragma unroll
                 for (int g = 0; g < 8; g++) {
@@ -270,13 +307,48 @@ void k_sweep(BatchD b, SweepD sw) {
                     if (r0 >= K) break;
                 }
             }
+            if (FULL && t >= next_flush) {
+                // the maxima of completed columns: everything left of the column the highest strip in band is working on
+                const int jdone = min(t - QHI[t], C + 1);
+                for (int col = flushed + lane; col < jdone; col += 64) {
+                    unsigned long long* e = &ring[(unsigned)col & (RING - 1)];
+                    const unsigned long long v = *e;
+                    *e = 0ull;
+                    gcmax[col] = __longlong_as_double((long long)v);
+                }
+                flushed = max(flushed, jdone);
+                next_flush = t + 64;
+            }
         } else {
-            bot_m = NINF; bot_s = NINF;
+            bot_m = NINF; bot_s = NINF; bot_e = NINF;
         }
         a0 = a1; a1 = a2;
         ql0 = ql1; ql1 = ql2;
     }
-    if (qcur >= 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
+    if (DIR == 0 && qcur >= 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
+    if (FULL)
+        for (int col = flushed + lane; col <= C; col += 64) gcmax[col] = __longlong_as_double((long long)ring[(unsigned)col & (RING - 1)]);
+}
+
+// forward-only batches: one wave per job
+template <int K, bool FD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 2 : 1, K <= 10 ? 2 : 1)))
+void k_sweep(BatchD b, SweepD sw) {
+    const JobD& J = b.jobs[blockIdx.x];
+    if (J.out->inert) return;
+    sweep_body<K, 0, false, FD>(b, sw, J, sw.sj[blockIdx.x], nullptr);
+}
+
+// Alignment::update batches: one wave per (job, direction), sweep job jd = 2 * job + direction
+template <int K, bool FD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 2 : 1, K <= 10 ? 2 : 1)))
+void k_sweep2(BatchD b, SweepD sw) {
+    __shared__ unsigned long long ring[RING];
+    const int jd = blockIdx.x;
+    const JobD& J = b.jobs[jd >> 1];
+    if (J.out->inert) return;
+    if ((jd & 1) == 0) sweep_body<K, 0, true, FD>(b, sw, J, sw.sj[jd], ring);
+    else sweep_body<K, 1, true, FD>(b, sw, J, sw.sj[jd], ring);
 }
 
 // the global maximum and its first cell — smallest column, then smallest row (cpp/Alignment.cpp:158, 270: strict '>' over columns
@@ -285,7 +357,7 @@ __global__ __launch_bounds__(64) void k_best(BatchD b, SweepD sw) {
     const JobD& J = b.jobs[blockIdx.x];
     JobOut* O = J.out;
     if (O->inert) return;
-    const SweepJob& SJ = sw.sj[blockIdx.x];
+    const SweepJob& SJ = sw.sj[blockIdx.x * sw.ndir];
     const StripBest* SB = sw.sb + SJ.sb_off;
     double v = 0.0;
     int bi = 0x7fffffff, bj = 0x7fffffff;
@@ -326,7 +398,7 @@ template <int K>
 __global__ __launch_bounds__(256) void k_backtrace_s(BatchD b, SweepD sw) {
     const JobD& J = b.jobs[blockIdx.x];
     StripCodes<K> src;
-    src.codes = sw.codes + sw.sj[blockIdx.x].codes_off;
+    src.codes = sw.codes + sw.sj[blockIdx.x * sw.ndir].codes_off;
     bt_walk(J, src);
 }
 
@@ -412,11 +484,13 @@ int sweep_guess_k(int W) {
 }
 static int next_k(int K) { for (int k : K_LIST) if (k > K) return k; return 0; }
 
-// bytes of step codes one job takes at strip height K
-double sweep_job_bytes(int n0, int C, int K) { return ((double)C + (n0 + K - 1) / K + 1) * 64.0 * K; }
-
 template <int K>
 static void sweep_launch_k(Runtime* rt, const BatchD& b, const SweepD& sw) {
+    if (sw.ndir == 2) {
+        if (b.fastdiv) hipLaunchKernelGGL((k_sweep2<K, true>), dim3(b.njobs * 2), dim3(64), 0, rt->stream, b, sw);
+        else hipLaunchKernelGGL((k_sweep2<K, false>), dim3(b.njobs * 2), dim3(64), 0, rt->stream, b, sw);
+        return;
+    }
     if (b.fastdiv) hipLaunchKernelGGL((k_sweep<K, true>), dim3(b.njobs), dim3(64), 0, rt->stream, b, sw);
     else hipLaunchKernelGGL((k_sweep<K, false>), dim3(b.njobs), dim3(64), 0, rt->stream, b, sw);
 }
@@ -425,29 +499,42 @@ static void bt_launch_k(Runtime* rt, const BatchD& b, const SweepD& sw) {
     hipLaunchKernelGGL((k_backtrace_s<K>), dim3(b.njobs), dim3(256), 0, rt->stream, b, sw);
 }
 
-// the strip tables of a batch at strip height K: job records, band table, qlo + the widest window (read back by the caller)
+// bytes one job takes at strip height K: step codes (forward), and with full = true the records of both directions
+double sweep_job_bytes(int n0, int C, int K, bool full) {
+    const double steps = (double)C + (n0 + K - 1) / K + 1;
+    return steps * 64.0 * K * (full ? 1.0 + 2 * 16.0 : 1.0);
+}
+
+// the strip tables of a batch at strip height K: sweep-job records (one per job and direction), band table, qlo / qhi + the
+// widest window (read back by the caller).  bt.ndir == 2: also the record offsets of both directions (JobD.mat_off, JobD.K).
 int sweep_prepare(Runtime* rt, Batch& bt, int K) {
     const BatchD& b = bt.d;
+    const int nd = bt.ndir;
     std::vector<SweepJob>& sj = bt.sjobs;
-    sj.resize(bt.jobs.size());
-    int64_t band_tot = 0, q_tot = 0, sb_tot = 0, code_tot = 0;
+    sj.resize(bt.jobs.size() * nd);
+    int64_t band_tot = 0, q_tot = 0, sb_tot = 0, code_tot = 0, rec_tot = 0;
     int maxT = 0;
     for (size_t k = 0; k < bt.jobs.size(); k++) {
-        const JobD& j = bt.jobs[k];
-        SweepJob s;
-        s.Q = (j.n0 + K - 1) / K;
-        s.T = j.C + s.Q;                         // steps t = j + q run 1 .. C + Q - 1
-        s.band_off = band_tot; band_tot += j.C + 2;
-        s.q_off = q_tot; q_tot += s.T + Q_PAD;
-        s.sb_off = sb_tot; sb_tot += std::max(s.Q, 1);
-        s.codes_off = code_tot; code_tot += (int64_t)s.T * 64 * K;
-        maxT = std::max(maxT, s.T);
-        sj[k] = s;
+        JobD& j = bt.jobs[k];
+        j.K = nd == 2 ? K : 0;
+        for (int d = 0; d < nd; d++) {
+            SweepJob s;
+            s.Q = (j.n0 + K - 1) / K;
+            s.T = j.C + s.Q;                         // steps t = column + strip run 1 .. C + Q - 1
+            s.band_off = band_tot; band_tot += j.C + 2;
+            s.q_off = q_tot; q_tot += s.T + Q_PAD;
+            s.sb_off = sb_tot; if (d == 0) sb_tot += std::max(s.Q, 1);
+            s.codes_off = code_tot; if (d == 0) code_tot += (int64_t)s.T * 64 * K;
+            if (nd == 2) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)s.T * 64 * K; }
+            maxT = std::max(maxT, s.T);
+            sj[k * nd + d] = s;
+        }
     }
-    bt.sweep_K = K; bt.sweep_maxT = maxT; bt.sweep_code_bytes = code_tot; bt.sweep_sb = sb_tot;
+    bt.sweep_K = K; bt.sweep_maxT = maxT; bt.sweep_code_bytes = code_tot; bt.sweep_sb = sb_tot; bt.sweep_recs = rec_tot;
     PS_TRY(rt->buf("sw_jobs").ensure(std::max<size_t>(sj.size(), 1) * sizeof(SweepJob)));
     PS_TRY(rt->buf("sw_band").ensure(std::max<int64_t>(band_tot, 1) * sizeof(int2)));
     PS_TRY(rt->buf("sw_qlo").ensure(std::max<int64_t>(q_tot, 1) * sizeof(int)));
+    PS_TRY(rt->buf("sw_qhi").ensure(std::max<int64_t>(q_tot, 1) * sizeof(int)));
     PS_TRY(rt->buf("sw_sb").ensure(std::max<int64_t>(sb_tot, 1) * sizeof(StripBest)));
     PS_TRY(rt->buf("sw_win").ensure(64));
     PS_TRY(rt->up(rt->buf("sw_jobs").p, sj.data(), sj.size() * sizeof(SweepJob)));
@@ -455,18 +542,20 @@ int sweep_prepare(Runtime* rt, Batch& bt, int K) {
     sw.sj = rt->buf("sw_jobs").as<SweepJob>();
     sw.band = rt->buf("sw_band").as<int2>();
     sw.qlo = rt->buf("sw_qlo").as<int>();
+    sw.qhi = rt->buf("sw_qhi").as<int>();
     sw.sb = (StripBest*)rt->buf("sw_sb").p;
     sw.maxwin = rt->buf("sw_win").as<int>();
     sw.codes = nullptr;
     sw.K = K;
+    sw.ndir = nd;
     PS_HIP(hipMemsetAsync(sw.maxwin, 0, sizeof(int), rt->stream));
-    hipLaunchKernelGGL(k_band, dim3((bt.maxC + 2 + 255) / 256, b.njobs), dim3(256), 0, rt->stream, b, sw);
-    hipLaunchKernelGGL(k_qlo, dim3((maxT + Q_PAD + 255) / 256, b.njobs), dim3(256), 0, rt->stream, b, sw);
+    hipLaunchKernelGGL(k_band, dim3((bt.maxC + 2 + 255) / 256, b.njobs * nd), dim3(256), 0, rt->stream, b, sw);
+    hipLaunchKernelGGL(k_qlo, dim3((maxT + Q_PAD + 255) / 256, b.njobs * nd), dim3(256), 0, rt->stream, b, sw);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
 
-// forward sweeps, maxima, backtrace and path scores of a prepared batch (the code pool is placed by the caller)
+// sweeps, maxima, backtrace and path scores of a prepared batch (the code / record pools are placed by the caller)
 int sweep_run(Runtime* rt, Batch& bt) {
     const BatchD& b = bt.d;
     SweepD& sw = bt.sd;
@@ -485,6 +574,7 @@ int sweep_run(Runtime* rt, Batch& bt) {
     PS_LAUNCH_CHECK();
     prof_end(rt, "fill", 0.0);
     hipLaunchKernelGGL(k_best, dim3(b.njobs), dim3(64), 0, rt->stream, b, sw);
+    if (bt.ndir == 2) PS_TRY(launch_prefix(rt, b, 2));   // running MaxInfo per column of both directions (the strip jobs' best cell is k_best's)
     switch (K) {
         case 4: bt_launch_k<4>(rt, b, sw); break;
         case 6: bt_launch_k<6>(rt, b, sw); break;

@@ -389,6 +389,12 @@ int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, in
     PS_TRY(rt->buf("vit_bp").ensure((size_t)ttot * NS * sizeof(short)));
     PS_TRY(rt->buf("vit_fwd").ensure((size_t)(nkeep ? ttot : 1) * NS * sizeof(double)));
     PS_TRY(rt->buf("vit_lik").ensure((size_t)R * NS * sizeof(double)));
+    if (nkeep > 0) {   // every allocation of the call before the first deviate is drawn: a caller may cut the batch again on PS_ERR_NOMEM
+        PS_TRY(rt->buf("vit_att").ensure(nkeep * sizeof(double)));
+        PS_TRY(rt->buf("vit_start").ensure(R * sizeof(int)));
+        PS_TRY(rt->buf("vit_rnd").ensure((size_t)nkeep * ttot * sizeof(double)));
+        PS_TRY(rt->buf("vit_path").ensure((size_t)nkeep * ttot * sizeof(short)));
+    }
     VitReg* d_regs = rt->buf("vit_regs").as<VitReg>();
     int* d_posreg = rt->buf("vit_posreg").as<int>();
     double* d_in = rt->buf("vit_in").as<double>();
@@ -436,10 +442,6 @@ int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, in
     }
     std::vector<double> att(nkeep);
     for (int k = 0; k < nkeep; k++) att[k] = mmin + (mmax - mmin) * k / (double)nkeep;
-    PS_TRY(rt->buf("vit_att").ensure(nkeep * sizeof(double)));
-    PS_TRY(rt->buf("vit_start").ensure(R * sizeof(int)));
-    PS_TRY(rt->buf("vit_rnd").ensure((size_t)nkeep * ttot * sizeof(double)));
-    PS_TRY(rt->buf("vit_path").ensure((size_t)nkeep * ttot * sizeof(short)));
     PS_TRY(rt->up(rt->buf("vit_att").p, att.data(), nkeep * sizeof(double)));
     PS_TRY(rt->up(rt->buf("vit_start").p, starts.data(), R * sizeof(int)));
     PS_HIP(hipMemcpyAsync(rt->buf("vit_rnd").p, h_rand, (size_t)nkeep * ttot * sizeof(double), hipMemcpyHostToDevice, rt->stream));

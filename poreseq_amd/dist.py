@@ -16,6 +16,7 @@ def init(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("PORESEQ_DEVICE", str(local))   # read by libporeseq_hip when it first touches the GPU
+    _pin_host_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     force = os.environ.get("PORESEQ_FORCE_PG") == "1"     # tests: exercise the collective path on one GPU
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
@@ -27,6 +28,25 @@ def init(backend=None):
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def _pin_host_cores(local, local_world):
+    """Several ranks on one node: each keeps to its own slice of the node's cores (7 driver threads + helper threads per rank
+    would otherwise be ~300 runnable threads wandering over 256 cores at 8 ranks) and caps the library's helper threads per call
+    at a quarter of the slice.  Done before anything touches the GPU; PORESEQ_NO_PIN=1 leaves affinity alone."""
+    if local_world <= 1 or os.environ.get("PORESEQ_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:
+        return None
+    mine = cores[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    os.environ.setdefault("PORESEQ_HOST_THREADS", str(max(2, per // 4)))
+    return mine
 
 
 def device():

@@ -50,8 +50,10 @@ def fwd_kernel(request):
     from poreseq_amd import _capi
     api = _capi.load_hip()
     api.set_sweep_min(0 if request.param == "sweep" else 1 << 30)
+    api.set_sweep2_min(0 if request.param == "sweep" else 1 << 30)
     yield request.param
     api.set_sweep_min(-1)
+    api.set_sweep2_min(-1)
 
 
 @pytest.fixture
@@ -59,5 +61,7 @@ def sweep_always():
     from poreseq_amd import _capi
     api = _capi.load_hip()
     api.set_sweep_min(0)
+    api.set_sweep2_min(0)
     yield
     api.set_sweep_min(-1)
+    api.set_sweep2_min(-1)

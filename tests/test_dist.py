@@ -241,3 +241,26 @@ def test_shard_plan_config5_on_eight_ranks_is_balanced():
     assert sorted(seen) == list(range(len(regions)))
     assert max(loads) - min(loads) <= max(lens)
     assert max(counts) - min(counts) <= 1
+
+
+def test_ranks_on_one_node_split_the_host_cores(monkeypatch):
+    """dist._pin_host_cores: disjoint, equal slices of the node's cores per local rank and a helper-thread cap per rank"""
+    from poreseq_amd import dist as psdist
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity")
+    before = os.sched_getaffinity(0)
+    if len(before) < 2:
+        pytest.skip("one core")
+    try:
+        monkeypatch.delenv("PORESEQ_HOST_THREADS", raising=False)
+        monkeypatch.delenv("PORESEQ_NO_PIN", raising=False)
+        a = psdist._pin_host_cores(0, 2)
+        os.sched_setaffinity(0, before)
+        b = psdist._pin_host_cores(1, 2)
+        assert a and b and not set(a) & set(b) and len(a) == len(b) == len(before) // 2
+        assert int(os.environ["PORESEQ_HOST_THREADS"]) == max(2, len(a) // 4)
+        os.sched_setaffinity(0, before)
+        assert psdist._pin_host_cores(0, 1) is None          # one rank per node: nothing to split
+    finally:
+        os.sched_setaffinity(0, before)
+        os.environ.pop("PORESEQ_HOST_THREADS", None)

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 : > gpurun_out/${TAG}.log
 for cfg in "$@"; do
     echo "== $cfg" >> gpurun_out/${TAG}.log
-    env $(echo "$cfg" | tr ' ' '\n' | grep '=' | grep -v '^--' | tr '\n' ' ') timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu --no-extras $(echo "$cfg" | tr ' ' '\n' | grep -v '^[A-Z_]*=' | tr '\n' ' ') 2>/dev/null | python -c "
+    env $(echo "$cfg" | tr ' ' '\n' | grep '=' | grep -v '^--' | tr '\n' ' ') timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu --no-extras $(echo "$cfg" | tr ' ' '\n' | grep -v '^[A-Z_0-9]*=' | tr '\n' ' ') 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
