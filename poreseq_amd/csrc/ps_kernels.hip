@@ -1086,51 +1086,106 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         for (int off = 1; off < 64; off <<= 1) span = max(span, __shfl_xor(span, off));
         double cm = 0.0, cs = 0.0, colmax = 0.0, lprev = 0.0;
         const bool is_t = mine && cc == trel;
-        for (int t = -1; t <= span; t++) {
-            const int i = base + t - c;
-            // value of (i, jc-1): matrix / carried chunk column for lane 0, left neighbour otherwise
-            double L = wave_shr1(cm);
-            if (c == 0) {
-                L = 0.0;
-                if (mine && i >= p0 && i <= p1 && i >= 1) {
-                    if (ch > 0) L = carry[i - p0];
-                    else if (sidx > 0) L = b.rec[rec_index(J, 0, i, sidx)].x;
-                }
+        // The common case — skewed matrices, the item's columns in one chunk, no invalid 5-mer among them — runs a branch-free step:
+        // every lane computes a cell on every step (on a clamped row outside its band) and what must not count is masked; the
+        // matrix reads walk the skewed storage with cursors instead of index arithmetic per step.  Values are those of the general
+        // loop below: candidates that are switched off there (no left / diagonal neighbour, top row) are -infinity, `lik_insert`
+        // or `0 + x` here, which lose to the floors exactly where the reference's never-assigned candidates do.
+        if (G < 64 && J.K == 0 && __ballot(mine && state < 0) == 0ull) {
+            const int P = J.P;
+            const double2* __restrict__ rf = b.rec + J.mat_off[0];
+            const double2* __restrict__ rb = b.rec + J.mat_off[1];
+            const double NINF = -__builtin_inf();
+            int i = base - 1 - c;                                    // row of this lane on step t = -1
+            const bool use_f = mine && c == 0 && sidx > 0;          // lane 0 reads the spliced forward column
+            const bool use_b = is_t && backind > 0;                  // the target lane reads the backward column
+            int fslot = i >= 0 ? i % P : 0, bslot = (n0 - i + 1) % P;
+            unsigned fidx = (unsigned)(max(i, 0) + sidx) * (unsigned)P + (unsigned)fslot;            // record of (i, sidx), forward matrix
+            unsigned bidx = (unsigned)(n0 - i + 1 + backind) * (unsigned)P + (unsigned)bslot;        // record of (n0 - i + 1, backind), backward matrix
+            const double log2pi = b.log2pi, off = J.lik_offset;
+            for (int t = -1; t <= span; t++) {
+                double L = wave_shr1(cm);
+                const bool vl = i >= p0 && i <= p1;
+                if (c == 0) { L = 0.0; if (use_f && vl && i >= 1) L = rf[fidx].x; }
+                const double D = lprev;
+                lprev = L;
+                const bool inb = mine && i >= i0 && i <= i1;
+                const double4 lv4 = levf[clampi(i, 1, n0) - 1];     // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
+                const double lev[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+                const double o = emission8<FD>(mr, lev, log2pi, off);
+                const bool vd = vl && i != p0, top = i == i0;
+                const double Lz = vl ? L : 0.0, Dz = vd ? D : 0.0;
+                const double um = top ? NINF : cm, us = top ? NINF : cs;
+                const double cSKIP = Lz + lsk, cMATCH = Dz + o, cIGN = Dz + lin;
+                const double cSTAY = um + o + lst, cEXT = us + o + lex, cINS = um + lin;
+                const double ns = fmax(fmax(top ? -BIG : 0.0, cSTAY), cEXT);
+                double nm = fmax(0.0, cSKIP);
+                nm = fmax(nm, cMATCH);
+                nm = fmax(nm, cINS);
+                nm = fmax(nm, cIGN);
+                nm = fmax(nm, ns);
+                cm = nm; cs = ns;                                    // (rows outside the band leave garbage that nothing reads: the next in-band row is a top row)
+                colmax = fmax(colmax, inb ? nm : 0.0);
+                const int jb = n0 - i + 1;
+                const bool hit = inb && is_t && jb >= bb0 && jb <= bb1;
+                double2 bv = make_double2(0.0, 0.0);
+                if (hit && use_b) bv = rb[bidx];
+                const double cand = fmax(nm + bv.x, ns + bv.y);
+                tm = hit ? fmax(tm, cand) : tm;
+                // next row: one anti-diagonal on, one slot on (forward); one back each (backward)
+                i++;
+                const bool fw = fslot + 1 == P;
+                fidx += fw ? 1u : (unsigned)P + 1u; fslot = fw ? 0 : fslot + 1;
+                const bool bw = bslot == 0;
+                bidx -= bw ? 1u : (unsigned)P + 1u; bslot = bw ? P - 1 : bslot - 1;
             }
-            const double D = lprev;
-            lprev = L;
-            if (mine && i >= i0 && i <= i1) {
-                double nm = 0.0, ns = 0.0;
-                if (state >= 0) {
-                    const double4 lv4 = levf[i - 1];   // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
-                    const double lev[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
-                    const double o = emission8<FD>(mr, lev, b.log2pi, J.lik_offset);
-                    const bool vl = i >= p0 && i <= p1, vd = i > p0 && i <= p1;
-                    const double cSKIP = vl ? L + lsk : lsk;
-                    const double cMATCH = vd ? D + o : o;
-                    const double cIGN = vd ? D + lin : 0.0;
-                    double cSTAY = -BIG, cEXT = -BIG, cINS = 0.0;
-                    if (i == i0) ns = -BIG;
-                    else { cSTAY = cm + o + lst; cINS = cm + lin; cEXT = cs + o + lex; }
-                    if (cSTAY > ns) ns = cSTAY;
-                    if (cEXT > ns) ns = cEXT;
-                    if (cSKIP > nm) nm = cSKIP;
-                    if (cMATCH > nm) nm = cMATCH;
-                    if (cINS > nm) nm = cINS;
-                    if (cIGN > nm) nm = cIGN;
-                    if (ns > nm) nm = ns;
-                }
-                cm = nm; cs = ns;
-                if (nm > colmax) colmax = nm;
-                if (is_t) {
-                    const int jb = n0 - i + 1;
-                    if (jb >= bb0 && jb <= bb1) {
-                        double2 bv = make_double2(0.0, 0.0);
-                        if (backind > 0) bv = b.rec[rec_index(J, 1, jb, backind)];
-                        tm = fmax(tm, fmax(nm + bv.x, ns + bv.y));
+        } else {
+            for (int t = -1; t <= span; t++) {
+                const int i = base + t - c;
+                // value of (i, jc-1): matrix / carried chunk column for lane 0, left neighbour otherwise
+                double L = wave_shr1(cm);
+                if (c == 0) {
+                    L = 0.0;
+                    if (mine && i >= p0 && i <= p1 && i >= 1) {
+                        if (ch > 0) L = carry[i - p0];
+                        else if (sidx > 0) L = b.rec[rec_index(J, 0, i, sidx)].x;
                     }
                 }
-                if (G == 64 && c == lastcol && ch + 1 < nchunk) carry[i - i0] = nm;
+                const double D = lprev;
+                lprev = L;
+                if (mine && i >= i0 && i <= i1) {
+                    double nm = 0.0, ns = 0.0;
+                    if (state >= 0) {
+                        const double4 lv4 = levf[i - 1];   // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
+                        const double lev[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+                        const double o = emission8<FD>(mr, lev, b.log2pi, J.lik_offset);
+                        const bool vl = i >= p0 && i <= p1, vd = i > p0 && i <= p1;
+                        const double cSKIP = vl ? L + lsk : lsk;
+                        const double cMATCH = vd ? D + o : o;
+                        const double cIGN = vd ? D + lin : 0.0;
+                        double cSTAY = -BIG, cEXT = -BIG, cINS = 0.0;
+                        if (i == i0) ns = -BIG;
+                        else { cSTAY = cm + o + lst; cINS = cm + lin; cEXT = cs + o + lex; }
+                        if (cSTAY > ns) ns = cSTAY;
+                        if (cEXT > ns) ns = cEXT;
+                        if (cSKIP > nm) nm = cSKIP;
+                        if (cMATCH > nm) nm = cMATCH;
+                        if (cINS > nm) nm = cINS;
+                        if (cIGN > nm) nm = cIGN;
+                        if (ns > nm) nm = ns;
+                    }
+                    cm = nm; cs = ns;
+                    if (nm > colmax) colmax = nm;
+                    if (is_t) {
+                        const int jb = n0 - i + 1;
+                        if (jb >= bb0 && jb <= bb1) {
+                            double2 bv = make_double2(0.0, 0.0);
+                            if (backind > 0) bv = b.rec[rec_index(J, 1, jb, backind)];
+                            tm = fmax(tm, fmax(nm + bv.x, ns + bv.y));
+                        }
+                    }
+                    if (G == 64 && c == lastcol && ch + 1 < nchunk) carry[i - i0] = nm;
+                }
             }
         }
         // MaxInfo: max over the new columns up to and including the target

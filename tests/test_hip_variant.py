@@ -2,6 +2,7 @@
 ScoreMutations with scoring_width 100 on random point edits, through the variant driver's start offsetting."""
 import copy
 import io
+import os
 
 import numpy as np
 import pytest
@@ -159,3 +160,43 @@ def test_chained_smith_waterman_strips_under_load_match_oracle():
     stop.set()
     bg.join()
     assert got == alone
+
+
+@pytest.mark.gpu
+def test_second_streams_on_priority_levels_finish_and_match():
+    """lock-step batches from several host threads, every runtime with a SECOND stream for its Smith-Waterman
+    batches on the next stream priority level (PORESEQ_FORCE_STREAM2=prio: the configuration of round 2's run that did not
+    finish), chained Smith-Waterman strips spinning on each other beside fills — under a hard time limit, results equal to the
+    default single-stream run.  (The library's default stays one stream per runtime: the second one buys nothing, DESIGN.md.)"""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import hashlib, sys, threading, copy\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from poreseq_amd import synth\n"
+        "from poreseq_amd.batch import RegionBatch\n"
+        "from poreseq_amd.poreseqcpp import PSAlign, swalign\n"
+        "from poreseq_amd.util import DEFAULT_PARAMS\n"
+        "P = dict(DEFAULT_PARAMS, verbose=0)\n"
+        "regs = [synth.make_region(5000, 6, 9100 + k, swalign, P) for k in range(12)]\n"
+        "out = [None] * 6\n"
+        "def work(t):\n"
+        "    pas = []\n"
+        "    for d, ev, _ in regs[2 * t:2 * t + 2]:\n"
+        "        pa = PSAlign(); pa.sequence, pa.events, pa.params = d, copy.deepcopy(ev), dict(P); pas.append(pa)\n"
+        "    with RegionBatch(pas) as rb:\n"
+        "        n = rb.Mutate(reps=2)\n"
+        "    out[t] = (n, [pa.sequence for pa in pas])\n"
+        "th = [threading.Thread(target=work, args=(t,)) for t in range(6)]\n"
+        "[t.start() for t in th]; [t.join() for t in th]\n"
+        "print('DIGEST', hashlib.sha1(repr(out).encode()).hexdigest())\n"
+    ) % (os.path.dirname(here), here)
+
+    def run(extra):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=420)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+
+    want = run({})
+    assert run({"PORESEQ_FORCE_STREAM2": "prio"}) == want
+    assert run({"PORESEQ_FORCE_STREAM2": "1", "PORESEQ_ONE_PRIORITY": "1"}) == want
