@@ -747,18 +747,28 @@ int guess_slots(const Align* a) {
     return std::min(1024, std::max(64, g));
 }
 
-// How many of the AlignData as[k0..] fit this runtime's device share when each event takes `ndir` sweeps (at least one)
+// Where the sub-batch of AlignData that starts at as[k0] ends when each event takes `ndir` sweeps: everything if it fits this
+// runtime's device share; otherwise the batch is cut into the fewest sub-batches that fit, of about equal size (a remainder of
+// two regions behind two full sub-batches would cost a whole launch's latency for a tenth of the work)
 static size_t fit_share(const std::vector<Align*>& as, size_t k0, int ndir) {
-    const double cap = device_share_bytes();
-    double bytes = 0;
-    size_t k = k0;
-    for (; k < as.size(); k++) {
+    const double cap = 1.05 * device_share_bytes();   // (realign() lets a batch take 1.2 shares before it asks for a split)
+    auto need = [&](size_t k) {
         const Align* a = as[k];
         const int P = guess_slots(a);
         double add = 0;
         for (int e = 0; e < a->E; e++)
             add += ndir == 1 ? fwd_job_bytes(a, a->n[e], (int)a->states.size()) : ((double)a->n[e] + a->states.size() + 1 + MAT_FRONT + MAT_BACK) * P * 18.0 * ndir;
-        if (k > k0 && bytes + add > cap) break;
+        return add;
+    };
+    double total = 0;
+    for (size_t k = k0; k < as.size(); k++) total += need(k);
+    if (total <= cap) return as.size();
+    const double target = total / std::ceil(total / cap);      // bytes per sub-batch, all about equal
+    double bytes = 0;
+    size_t k = k0;
+    for (; k < as.size(); k++) {
+        const double add = need(k);
+        if (k > k0 && (bytes + add > cap || bytes + 0.5 * add > target)) break;
         bytes += add;
     }
     return k;
