@@ -751,7 +751,7 @@ int guess_slots(const Align* a) {
 // runtime's device share; otherwise the batch is cut into the fewest sub-batches that fit, of about equal size (a remainder of
 // two regions behind two full sub-batches would cost a whole launch's latency for a tenth of the work)
 static size_t fit_share(const std::vector<Align*>& as, size_t k0, int ndir) {
-    const double cap = 1.05 * device_share_bytes();   // (realign() lets a batch take 1.2 shares before it asks for a split)
+    const double cap = device_share_bytes();
     auto need = [&](size_t k) {
         const Align* a = as[k];
         const int P = guess_slots(a);
