@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_OF = {"fill": "k_fill", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}
+KERNEL_OF = {"fill": "k_fill", "sweep": "k_sweep", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}
 
 
 def _cpu_region_worker(job):
@@ -277,13 +277,23 @@ def main():
             roof = {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": int(launches),
                     "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": nbytes / max(launches, 1),
-                    "sweeps_per_launch": units / max(launches, 1) if dom == "fill" else None,
+                    "sweeps_per_launch": units / max(launches, 1) if dom in ("fill", "sweep") else None,
                     "measured": "HIP events per launch inside the %d timed step(s), %d lock-step batches in flight (one stream each): a "
                                 "launch's duration includes what it shares the chip with" % (args.steps, NB),
                     "all_kernel_classes_ms_per_step": {c: v[0] / max(args.steps, 1) for c, v in tot.items()}}
             # aggregate rate of the class over the wall time of the steps (launches of different batches overlap)
             roof["aggregate_alg_gbs"] = (nbytes / 1e9) / dt if dt > 0 else None
             roof["launches_in_flight_mean"] = (ms / 1e3) / dt if dt > 0 else None
+            # both DP-fill kernels by the same accounting (18 B per forward cell, 16 per backward cell): k_fill = a workgroup
+            # per sweep, score matrices written (Alignment::update batches and small forward batches); k_sweep = a wavefront per sweep,
+            # one byte per cell written (forward-only batches of 400 alignments and more)
+            roof["fill_kernels"] = {}
+            for c in ("fill", "sweep"):
+                cms, cl, cb, cu = tot[c]
+                if cms > 0:
+                    roof["fill_kernels"][KERNEL_OF[c]] = {"launches": int(cl), "avg_launch_ms": cms / max(cl, 1), "sweeps_per_launch": cu / max(cl, 1),
+                                                          "alg_bytes_per_launch": cb / max(cl, 1), "achieved": (cb / 1e9) / (cms / 1e3),
+                                                          "frac": (cb / 1e9) / (cms / 1e3) / HBM_PEAK_GBS, "sweeps_per_step": cu / max(args.steps, 1)}
             if not args.no_extras:
                 # the same kernel class with the chip to itself: one lock-step batch of the timed size, alone, event pair read after
                 # every launch (the kernel's own quality; the figures above include what a launch shares the chip with)
@@ -297,23 +307,23 @@ def main():
                                                "achieved": (ib / 1e9) / (ims / 1e3), "frac": (ib / 1e9) / (ims / 1e3) / HBM_PEAK_GBS,
                                                "launches": int(il)}
             # HBM-side bytes per launch cannot be collected from inside this process: rocprofv3 --pmc on this very command
-            # (tools/pmc_bench.sh) writes profiles/r02_traffic.json; it is used only if its launch shape matches the live pass
+            # (tools/pmc_bench.sh) writes profiles/r03_traffic.json; it is used only if its launch shape matches the live pass
             try:
-                with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
                     tj = json.load(fh)
                 tk = tj["kernels"].get(KERNEL_OF[dom])
                 same = (tk and tj.get("length") == args.length and tj.get("events") == args.events and tj.get("regions_per_batch") == max(1, R // NB)
                         and abs(tk["alg_bytes_per_launch"] / roof["alg_bytes_per_launch"] - 1.0) < 0.10)
                 if same:
                     roof["traffic"] = tk["fetch_bytes_per_launch"] + tk["write_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r02_traffic.json: " + tj.get("source", "")
+                    roof["traffic_source"] = "profiles/r03_traffic.json: " + tj.get("source", "")
                     roof["schedule_traffic_gb_per_region"] = tj.get("whole_schedule", {}).get("gb_per_region")
                 else:
-                    roof["traffic_source"] = "profiles/r02_traffic.json ignored: measured on a different launch shape"
+                    roof["traffic_source"] = "profiles/r03_traffic.json ignored: measured on a different launch shape"
             except (OSError, ValueError, KeyError, ZeroDivisionError):
                 pass
             out["roofline"] = roof
-            sched = {"fill_sweeps": tot["fill"][3] / max(args.steps, 1), "score_items": tot["score"][3] / max(args.steps, 1)}
+            sched = {"fill_sweeps": (tot["fill"][3] + tot["sweep"][3]) / max(args.steps, 1), "score_items": tot["score"][3] / max(args.steps, 1)}
 
         # ---- parity spot-check + CPU baseline (oracle / reference: checker and baseline only, never the thing measured) ----
         if cpu_pre is not None:

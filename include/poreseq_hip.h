@@ -191,7 +191,7 @@ int ps_set_sweep_min(int32_t min_alignments);
 int ps_set_sweep2_min(int32_t min_sweeps);
 
 /* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
- * algorithmic bytes of the named kernel class ("fill", "score", "viterbi", "sw") since reset. */
+ * algorithmic bytes of the named kernel class ("fill" = k_fill, "sweep" = k_sweep / k_sweep2, "score", "viterbi", "sw") since reset. */
 /* ps_prof_enable(1) makes every hot-kernel launch be bracketed by HIP events on the library's stream
  * (one extra synchronisation per launch: use it in a separate, untimed pass); ps_prof_enable(2) queues the
  * event pairs instead and reads them when the profile is asked for (no synchronisation per launch: usable
@@ -199,7 +199,7 @@ int ps_set_sweep2_min(int32_t min_sweeps);
 int ps_prof_enable(int32_t on);
 int ps_prof_reset(void);
 int ps_prof_get(const char* name, double* ms, int64_t* launches, double* alg_bytes);
-/* work units of the class since reset: "fill" = sweeps (one alignment, one direction), "score" = (event, edit) items */
+/* work units of the class since reset: "fill" / "sweep" = sweeps (one alignment, one direction), "score" = (event, edit) items */
 int ps_prof_units(const char* name, double* units);
 
 #ifdef __cplusplus

@@ -667,7 +667,7 @@ static int realign_sweep(Runtime* rt, Batch& b, double cap) {
             PS_HIP(hipMemsetAsync(b.d.cmax, 0, b.ncols * sizeof(double), rt->stream));
         }
     }
-    if (rt->prof_on) { rt->prof["fill"].bytes += b.fill_alg_bytes(); rt->prof["fill"].units += (double)b.d.njobs * b.ndir; }
+    if (rt->prof_on) { rt->prof["sweep"].bytes += b.fill_alg_bytes(); rt->prof["sweep"].units += (double)b.d.njobs * b.ndir; }
     PS_TRY(sweep_run(rt, b));
     PS_TRY(launch_updaterefs(rt, b.d));
     return PS_OK;

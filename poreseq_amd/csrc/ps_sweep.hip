@@ -572,7 +572,7 @@ int sweep_run(Runtime* rt, Batch& bt) {
         default: return fail(PS_ERR_BAD_ARG, "sweep_run: strip height");
     }
     PS_LAUNCH_CHECK();
-    prof_end(rt, "fill", 0.0);
+    prof_end(rt, "sweep", 0.0);
     hipLaunchKernelGGL(k_best, dim3(b.njobs), dim3(64), 0, rt->stream, b, sw);
     if (bt.ndir == 2) PS_TRY(launch_prefix(rt, b, 2));   // running MaxInfo per column of both directions (the strip jobs' best cell is k_best's)
     switch (K) {

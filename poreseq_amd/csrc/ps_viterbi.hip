@@ -16,6 +16,8 @@
 // Max-plus values (liks, back-pointers) are bit-exact; forward probabilities use device exp / log
 // (fwd^atten as exp(atten * log fwd)) and tree sums, i.e. agree to a few ulp; they only weight the
 // random back-traces.
+#include <atomic>
+
 #include "ps_internal.h"
 
 namespace ps {
@@ -65,6 +67,49 @@ __global__ __launch_bounds__(256) void k_vit_obs(const VitReg* __restrict__ regs
             if (drop > nl - 2) drop = 0;
             double s = 0.0;
             for (int k = drop; k < nl; k++) s += v[k];
+            r = s / (double)(nl - drop);
+        } else {
+            r = nl == 1 ? v[0] : 0.0;
+        }
+        obs[(size_t)t * NS + st] = r;
+        eobs[(size_t)t * NS + st] = exp(r);   // V_LIK multiplies the forward sum by exp(obs), cpp/Viterbi.cpp:91
+    }
+}
+
+// The same with the per-state list of emissions in LDS instead of a private array (which the compiler keeps in scratch memory:
+// 70 GB of HBM traffic per launch at 20 regions): thread t owns the column v[k * 256 + t] (one bank group per 32 threads:
+// conflict-free), k < VE = events of the deepest region of the call (up to 72: 144 KB of the CU's 160 KB).
+__global__ __launch_bounds__(256) void k_vit_obs_lds(const VitReg* __restrict__ regs, const int* __restrict__ pos_reg, const double* __restrict__ obsin,
+                                                     double log2pi, double* __restrict__ obs, double* __restrict__ eobs) {
+    extern __shared__ double vit_v[];
+    const int t = blockIdx.x;
+    const VitReg R = regs[pos_reg[t]];
+    const int E = R.E;
+    const double* in = obsin + R.in_off + (size_t)(t - R.t_off) * E * 4;
+    double* v = vit_v + threadIdx.x;
+    for (int st = threadIdx.x; st < NS; st += 256) {
+        int nl = 0;
+        for (int e = 0; e < E; e++) {
+            if (in[e * 4 + 3] == 0.0) continue;
+            const double* gm = R.model + (size_t)e * 6 * NS;
+            ModelRowV m = {gm[st], gm[NS + st], gm[2 * NS + st], gm[3 * NS + st], gm[4 * NS + st], gm[5 * NS + st]};
+            const double l = emission_v(m, in[e * 4 + 0], in[e * 4 + 1], in[e * 4 + 2], log2pi);
+            // insertion into ascending order (std::sort result is unique for distinct/equal doubles)
+            int k = nl++;
+            while (k > 0) {
+                const double w = v[(k - 1) * 256];
+                if (!(w > l)) break;
+                v[k * 256] = w;
+                k--;
+            }
+            v[k * 256] = l;
+        }
+        double r;
+        if (nl > 1) {
+            int drop = (int)floor(nl * 0.25);
+            if (drop > nl - 2) drop = 0;
+            double s = 0.0;
+            for (int k = drop; k < nl; k++) s += v[k * 256];
             r = s / (double)(nl - drop);
         } else {
             r = nl == 1 ? v[0] : 0.0;
@@ -408,7 +453,15 @@ int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, in
     for (int r = 0; r < R; r++)
         if (regions[r].T) PS_TRY(rt->up(d_in + regs[r].in_off, regions[r].obsin, (size_t)regions[r].T * regions[r].E * 4 * sizeof(double)));
     prof_begin(rt);
-    if (maxE <= 64) hipLaunchKernelGGL(k_vit_obs<64>, dim3((unsigned)ttot), dim3(256), 0, rt->stream, d_regs, d_posreg, d_in, std::log(2 * M_PI), d_obs, d_eobs);
+    if (maxE <= 72) {
+        static std::atomic<bool> attr(false);
+        if (!attr.load(std::memory_order_acquire)) {
+            PS_HIP(hipFuncSetAttribute((const void*)k_vit_obs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr.store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(k_vit_obs_lds, dim3((unsigned)ttot), dim3(256), (size_t)256 * std::max(maxE, 1) * sizeof(double), rt->stream, d_regs, d_posreg, d_in,
+                           std::log(2 * M_PI), d_obs, d_eobs);
+    } else if (maxE <= 64) hipLaunchKernelGGL(k_vit_obs<64>, dim3((unsigned)ttot), dim3(256), 0, rt->stream, d_regs, d_posreg, d_in, std::log(2 * M_PI), d_obs, d_eobs);
     else hipLaunchKernelGGL(k_vit_obs<256>, dim3((unsigned)ttot), dim3(256), 0, rt->stream, d_regs, d_posreg, d_in, std::log(2 * M_PI), d_obs, d_eobs);
     hipLaunchKernelGGL(k_vit_steps, dim3(R), dim3(1024), 0, rt->stream, d_regs, d_obs, d_eobs, skip, stay, std::log(skip), std::log(stay),
                        std::log(0.25), d_bp, d_fwd, d_lik, nkeep ? 1 : 0);
