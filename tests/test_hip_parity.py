@@ -189,8 +189,8 @@ def test_sw_parity_and_properties():
 
 
 def test_sw_all_strip_widths_and_super_strips_match_oracle():
-    """Every column-per-lane variant of the fill (4 / 8 / 16), a second super-strip (> 16384 columns), repeats
-    (many equal maxima: the column-major first one must start the traceback) and unrelated sequences."""
+    """Both column-per-lane variants of the fill (4 / 8), several super-strips, long near-identical pairs (scores of 60 000),
+    repeats (many equal maxima: the column-major first one must start the traceback) and unrelated sequences."""
     rng = np.random.default_rng(77)
     cases = []
     for n1, n2 in [(4100, 4096), (4096, 4097), (6000, 8192), (3000, 8193), (9000, 9500), (2500, 16400), (1300, 17000)]:
@@ -202,17 +202,22 @@ def test_sw_all_strip_widths_and_super_strips_match_oracle():
     cases.append((unit * 60, unit * 130))                       # tandem repeat: ties everywhere
     cases.append((synth.random_sequence(rng, 5000), synth.random_sequence(rng, 5200)))   # unrelated
     cases.append(("ACGT" * 300, "TGCA" * 1100))
+    s1 = synth.random_sequence(rng, 12084)                      # long, nearly identical: scores of 60 000
+    cases.append((s1, synth.corrupt(rng, s1, 0.002, 0.002, 0.002)))
+    cases.append((s1 + "ACGTT", s1 + "ACGTT"))
+    cases.append(("A" * 2600, "A" * 2700))                      # a whole super-strip of ties and a perfect diagonal
     want = [B.oracle_swalign(s1, s2) for s1, s2 in cases]
-    for env in (None, "8"):                      # the default 4-columns-per-lane build and the 8-column one
-        if env:
-            os.environ["PORESEQ_SW_K"] = env
+    for var, val in ((None, None), ("PORESEQ_SW_K", "8")):      # the default 4-columns-per-lane build and the 8-column one
+        if var:
+            os.environ[var] = val
         try:
             for (s1, s2), b in zip(cases, want):
                 a = swalign(s1, s2)
-                assert a[1] == b[1], (len(s1), len(s2), env)
+                assert a[1] == b[1], (len(s1), len(s2), var)
                 assert (a[0] == b[0]) or (np.isnan(a[0]) and np.isnan(b[0]))
         finally:
-            os.environ.pop("PORESEQ_SW_K", None)
+            if var:
+                os.environ.pop(var, None)
 
 
 def test_edge_cases_match_oracle():
