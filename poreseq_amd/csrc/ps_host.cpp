@@ -1134,17 +1134,33 @@ static int greedy_apply(Align* a, std::vector<Mut>& muts, std::vector<Mut>* late
     }
     if (muts.empty()) return 0;
     bool changed = false;
-    for (size_t i = 0; i < muts.size(); i++) {
-        if (muts[i].score < 0) { later->push_back(muts[i]); continue; }
+    // cpp/MakeMutations.cpp:95-139 with the edits' numbers in flat arrays: the inner loop over all later edits (defer the ones
+    // within `spacing` of the applied edit, shift the ones behind it) is then a branch-free integer loop the compiler vectorises —
+    // a Mutate list has ~3 000 surviving edits, 4.5 million pair visits per region and call
+    const size_t n = muts.size();
+    std::vector<int> st(n), ml(n), ol(n), pos(n), dfr(n, 0);
+    for (size_t k = 0; k < n; k++) {
+        st[k] = muts[k].start; ml[k] = (int)muts[k].mut.size(); ol[k] = (int)muts[k].orig.size();
+        pos[k] = muts[k].score > 0 ? 1 : 0;
+    }
+    for (size_t i = 0; i < n; i++) {
+        muts[i].start = st[i];
+        if (dfr[i] || muts[i].score < 0) { if (dfr[i]) muts[i].score = -1; later->push_back(muts[i]); continue; }
         a->bases = apply_edit(a->bases, muts[i]);
         changed = true;
         nb += (int)std::max(muts[i].orig.size(), muts[i].mut.size());
-        for (size_t j = i + 1; j < muts.size(); j++) {
-            const int lo = std::max(muts[i].start, muts[j].start);
-            const int hi = (int)std::min(muts[i].start + muts[i].mut.size(), muts[j].start + muts[j].mut.size());
-            if (lo < hi + spacing && muts[j].score > 0) { muts[j].score = -1; continue; }
-            if ((size_t)muts[j].start >= muts[i].start + muts[i].orig.size())
-                muts[j].start += (int)(muts[i].mut.size() - muts[i].orig.size());
+        const int si = st[i], ei = si + ml[i], oi = si + ol[i], d = ml[i] - ol[i];
+        int* __restrict__ pst = st.data();
+        int* __restrict__ ppos = pos.data();
+        int* __restrict__ pdf = dfr.data();
+        const int* __restrict__ pml = ml.data();
+        for (size_t j = i + 1; j < n; j++) {
+            const int sj = pst[j];
+            const int lo = std::max(si, sj), hi = std::min(ei, sj + pml[j]);
+            const int hit = (lo < hi + spacing) & ppos[j];          // overlaps the applied edit (with spacing) and still has a positive score: deferred
+            ppos[j] &= ~hit;
+            pdf[j] |= hit;
+            pst[j] = sj + ((!hit & (sj >= oi)) ? d : 0);            // (a deferred edit keeps its start: the reference `continue`s before the shift)
         }
     }
     if (changed) a->states = states_of(a->bases);
