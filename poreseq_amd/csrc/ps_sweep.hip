@@ -134,7 +134,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     struct Ahead { v4i bd; int sp, sc; };   // bd = {p0, p1, i0, i1} of columns j - 1, j; sp / sc = 5-mer of column j - 1 / j
     auto fetch = [&](int tt, int ql) -> Ahead {
         const int q = ql + ((lane - ql) & 63);
-        const int j = clampi(tt - q, 1, C);
+        const int j = clampi(tt - q, 1, max(C, 1));   // (a sequence without a 5-mer has no live step; its prefetches still need an address)
         Ahead a;
         a.bd = *(const PS_GLOBAL v4i_a4*)(band + 2 * (j - 1));
         typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));

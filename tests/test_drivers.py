@@ -34,6 +34,15 @@ def test_merge_seqs_equals_reference_function():
         assert consensus.merge_seqs(c["seq1"], c["seq2"], c["overlap"], swalign=B.oracle_swalign) == c["merged"]
 
 
+@pytest.mark.gpu
+def test_hip_merge_seqs_equals_reference_function():
+    """the same vectors (merge_fasta.py:8-39 run in memory) with the HIP Smith-Waterman behind `swalign`"""
+    from poreseq_amd.poreseqcpp import swalign
+    for c in Z["merge"]:
+        assert consensus.merge_seqs(c["seq1"], c["seq2"], c["overlap"], swalign=swalign) == c["merged"]
+        assert consensus.merge_seqs(c["seq1"], c["seq2"], c["overlap"]) == c["merged"]        # the driver's default backend is the HIP library
+
+
 def test_vary_params_equals_reference_function():
     v = Z["vary"]
     params = dict(zip(v["params_keys"], v["params_vals"]))
