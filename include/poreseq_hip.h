@@ -121,6 +121,12 @@ int ps_find_mutations(ps_align* a, int32_t n_seqs, const int64_t* seq_off, const
 /* ScoreMutations (cpp/MakeMutations.cpp:23-69): same order as the input list.  Re-aligns
  * every event as a side effect, as the reference does. */
 int ps_score_mutations(ps_align* a, const ps_muts* muts, ps_muts** out_scored);
+/* The terms of that sum instead of the sum: deltas[e * n_muts + m] = what event e adds to the score of edit m
+ * (cpp/MakeMutations.cpp:51: score[m] = -1e-6 + delta[0][m] + delta[1][m] + ... in event order).  For drivers that shard the
+ * EVENTS of one region over several GPUs (second axis): every rank scores its events, the deltas are
+ * gathered and every rank adds them up in the reference's order (poreseq_amd.dist.score_mutations_event_sharded).
+ * Events are re-aligned as by ps_score_mutations.  deltas needs n_events * n_muts doubles. */
+int ps_score_mutation_deltas(ps_align* a, const ps_muts* muts, double* deltas);
 /* MakeMutations (cpp/MakeMutations.cpp:74-146): greedy application, returns mutated-base count. */
 int ps_make_mutations(ps_align* a, const ps_muts* scored, int32_t* n_bases);
 

@@ -338,19 +338,25 @@ struct Aligner {
 
 // ---------------------------------------------------------------- batch drivers
 // ref: cpp/MakeMutations.cpp:23-69
-std::vector<Mut> score_mutations(Data& d, const std::vector<Mut>& muts) {
+// deltas (optional): [events][edits], every event's term of every edit's sum
+std::vector<Mut> score_mutations(Data& d, const std::vector<Mut>& muts, double* deltas = nullptr) {
     std::vector<Mut> out(muts);
     for (auto& m : out) m.score = -1e-6;
     std::vector<Aligner> al;
     for (auto& e : d.ev) al.emplace_back(d.seq, e, d.par);
+    size_t ei = 0;
     for (auto& a : al) {
         a.update(d.seq);
         for (size_t i = 0; i < out.size(); i++) {
+            if (deltas) deltas[ei * out.size() + i] = 0.0;
             if ((size_t)muts[i].start > d.seq.bases.size()) continue;
             Seq ms = apply_edit(d.seq, muts[i]);
-            out[i].score += a.score_edit(muts[i], ms);
+            const double dl = a.score_edit(muts[i], ms);
+            out[i].score += dl;
+            if (deltas) deltas[ei * out.size() + i] = dl;
         }
         a.clear();
+        ei++;
     }
     return out;
 }
@@ -860,6 +866,12 @@ int ps_score_mutations(ps_align* a, const ps_muts* in, ps_muts** out) {
     if (!a || !in || !out) return fail(PS_ERR_BAD_ARG, "ps_score_mutations");
     for (auto& x : in->v) if (x.start < 0) return fail(PS_ERR_BAD_ARG, "negative mutation start");
     ps_muts* m = new ps_muts(); m->v = score_mutations(a->d, in->v); *out = m;
+    return PS_OK;
+}
+int ps_score_mutation_deltas(ps_align* a, const ps_muts* in, double* deltas) {
+    if (!a || !in || !deltas) return fail(PS_ERR_BAD_ARG, "ps_score_mutation_deltas");
+    for (auto& x : in->v) if (x.start < 0) return fail(PS_ERR_BAD_ARG, "negative mutation start");
+    (void)score_mutations(a->d, in->v, deltas);
     return PS_OK;
 }
 int ps_make_mutations(ps_align* a, const ps_muts* in, int32_t* nb) {

@@ -167,6 +167,8 @@ int ps_score_mutations(ps_align* a, const ps_muts* in, ps_muts** out) {
     ps_muts* m = new ps_muts(); m->v = ScoreMutations(a->d, mi); *out = m;
     return PS_OK;
 }
+// (the reference only returns the sums: not available from its public functions)
+int ps_score_mutation_deltas(ps_align*, const ps_muts*, double*) { return PS_ERR_UNSUPPORTED; }
 int ps_make_mutations(ps_align* a, const ps_muts* in, int32_t* nb) {
     *nb = MakeMutations(a->d, in->v);
     return PS_OK;

@@ -59,6 +59,7 @@ SYMBOLS = {
     "ps_find_point_mutations": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ps_find_mutations": (C.c_int, [C.c_void_p, C.c_int32, c_i64p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "ps_score_mutations": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ps_score_mutation_deltas": (C.c_int, [C.c_void_p, C.c_void_p, c_dp]),
     "ps_make_mutations": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p]),
     "ps_viterbi_mutate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -249,6 +250,13 @@ class CApi:
     def score_mutations(self, h, hm):
         out = C.c_void_p()
         self.check(self.lib.ps_score_mutations(h, hm, C.byref(out)))
+        return out
+
+    def score_mutation_deltas(self, h, hm, n_events, n_muts):
+        """[n_events][n_muts] float64: every event's term of every edit's score (their sum in event order + -1e-6 is the score)"""
+        out = np.zeros((int(n_events), int(n_muts)), dtype=np.float64)
+        if out.size:
+            self.check(self.lib.ps_score_mutation_deltas(h, hm, _dp(out)))
         return out
 
     def make_mutations(self, h, hm):

@@ -148,6 +148,13 @@ int ps_score_mutations(ps_align* a, const ps_muts* in, ps_muts** out) {
     *out = m.release();
     return PS_OK;
 }
+int ps_score_mutation_deltas(ps_align* a, const ps_muts* in, double* deltas) {
+    if (!a || !in || !deltas) return fail(PS_ERR_BAD_ARG, "ps_score_mutation_deltas");
+    NEED_RT();
+    std::vector<Mut> scored;
+    std::vector<double*> dout(1, deltas);
+    return score_mutations_multi(rt, {&a->a}, {&in->v}, {&scored}, &dout);
+}
 int ps_make_mutations(ps_align* a, const ps_muts* in, int32_t* nb) {
     if (!a || !in || !nb) return fail(PS_ERR_BAD_ARG, "ps_make_mutations");
     NEED_RT();

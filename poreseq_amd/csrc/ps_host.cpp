@@ -944,13 +944,15 @@ static void plan_tables(const Align* a, const std::vector<Mut>& muts, EditPlan* 
 // ScoreMutations, cpp/MakeMutations.cpp:23-69, for several AlignData at once: one realign launch chain over all their
 // events (forward + backward of one event share a workgroup), then the edit scoring of each
 int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
-                          const std::vector<std::vector<Mut>*>& outs) {
+                          const std::vector<std::vector<Mut>*>& outs, const std::vector<double*>* delta_out) {
     if (fit_share(as, 0, 2) < as.size()) {   // sub-batches that fit this runtime's share of the device
         for (size_t k0 = 0; k0 < as.size();) {
             const size_t k1 = fit_share(as, k0, 2);
+            std::vector<double*> dsub;
+            if (delta_out) dsub.assign(delta_out->begin() + k0, delta_out->begin() + k1);
             PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin() + k0, as.begin() + k1),
                                          std::vector<const std::vector<Mut>*>(muts.begin() + k0, muts.begin() + k1),
-                                         std::vector<std::vector<Mut>*>(outs.begin() + k0, outs.begin() + k1)));
+                                         std::vector<std::vector<Mut>*>(outs.begin() + k0, outs.begin() + k1), delta_out ? &dsub : nullptr));
             k0 = k1;
         }
         return PS_OK;
@@ -989,10 +991,12 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         const int rc = realign(rt, b, R > 1 ? 1.2 * device_share_bytes() : 0.0);
         if (rc == PS_SPLIT) {   // bands wider than fit_share guessed: two halves, one after the other
             const size_t h = as.size() / 2;
+            std::vector<double*> d0, d1;
+            if (delta_out) { d0.assign(delta_out->begin(), delta_out->begin() + h); d1.assign(delta_out->begin() + h, delta_out->end()); }
             PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin(), as.begin() + h), std::vector<const std::vector<Mut>*>(muts.begin(), muts.begin() + h),
-                                         std::vector<std::vector<Mut>*>(outs.begin(), outs.begin() + h)));
+                                         std::vector<std::vector<Mut>*>(outs.begin(), outs.begin() + h), delta_out ? &d0 : nullptr));
             return score_mutations_multi(rt, std::vector<Align*>(as.begin() + h, as.end()), std::vector<const std::vector<Mut>*>(muts.begin() + h, muts.end()),
-                                         std::vector<std::vector<Mut>*>(outs.begin() + h, outs.end()));
+                                         std::vector<std::vector<Mut>*>(outs.begin() + h, outs.end()), delta_out ? &d1 : nullptr);
         }
         PS_TRY(rc);
     }
@@ -1060,11 +1064,17 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         }
     }
     PS_TRY(launch_score(rt, b.d, sab.as<ScoreArgs>(), sas));
+    std::vector<double*> dl(R, nullptr);
     for (int k = 0; k < R; k++)
-        if (plan[k].M && as[k]->E) PS_TRY(rt->down(&sc[k], sas[k].score, (size_t)plan[k].M));
+        if (plan[k].M && as[k]->E) {
+            PS_TRY(rt->down(&sc[k], sas[k].score, (size_t)plan[k].M));
+            if (delta_out && (*delta_out)[k]) PS_TRY(rt->down(&dl[k], sas[k].delta, (size_t)as[k]->E * plan[k].M));
+        }
     PS_HIP(hipStreamSynchronize(rt->stream));
-    for (int k = 0; k < R; k++)
+    for (int k = 0; k < R; k++) {
         if (sc[k]) for (int i = 0; i < plan[k].M; i++) (*outs[k])[i].score = sc[k][i];
+        if (dl[k]) memcpy((*delta_out)[k], dl[k], (size_t)as[k]->E * plan[k].M * sizeof(double));
+    }
     tk.lap("score edits");
     return PS_OK;
 }

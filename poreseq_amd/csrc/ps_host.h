@@ -114,8 +114,9 @@ int live_runtimes();   // host threads that currently own a runtime
 int guess_slots(const Align* a);   // anti-diagonal footprint realign() will probably choose
 double device_share_bytes();   // this runtime's share of the device memory for DP matrices
 int make_mutations_multi(Runtime* rt, const std::vector<Align*>& as, std::vector<std::vector<Mut>> muts, std::vector<int>* nbases);
+// delta_out (optional): per AlignData a host array [E][M] receiving every event's term of every edit's score
 int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
-                          const std::vector<std::vector<Mut>*>& outs);
+                          const std::vector<std::vector<Mut>*>& outs, const std::vector<double*>* delta_out = nullptr);
 int score_mutations(Runtime* rt, Align* a, const std::vector<Mut>& muts, std::vector<Mut>* out);
 void find_point_mutations(const Align* a, std::vector<Mut>* out);
 int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases);

@@ -135,6 +135,49 @@ def gather_regions(local_results, n_regions, max_events):
     return out
 
 
+def score_mutations_event_sharded(pa, muts, make_pa=None):
+    """`pa.ScoreMutations(muts)` with the EVENTS of the region dealt to the ranks (second axis: fewer regions
+    than GPUs — config #4's six regions on eight — or one region's latency): rank r scores events r, r + world, ... (the fills are
+    per event: nothing is computed twice), the per-event terms are exchanged with one all_gather (E x M doubles: 6.4 MB for a
+    Refine list at 10 events; RCCL over xGMI under nccl), and every rank adds them up in the reference's event order
+    (MakeMutations.cpp:51: score = -1e-6, then += delta per event) — bit-identical to the unsharded call, where an all-reduce
+    would sum in another order.  `make_pa(events) -> PSAlign` builds this rank's sub-alignment (default: a copy of `pa` with the
+    rank's events).  Returns the list of MutationScore on every rank.  The events of `pa` are not re-aligned (the reference's
+    Python `ScoreMutations` discards the re-alignment too, pyx:310-345)."""
+    import copy as _copy
+    from .util import MutationScore
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    E, M = len(pa.events), len(muts)
+    mine = list(range(rank, E, world))
+    if make_pa is None:
+        def make_pa(events):
+            sub = type(pa)()
+            sub.sequence, sub.events, sub.params = pa.sequence, [_copy.deepcopy(e) for e in events], dict(pa.params)
+            return sub
+    local = make_pa([pa.events[e] for e in mine]).ScoreMutationDeltas(muts) if mine and M else np.zeros((0, M))
+    per = (E + world - 1) // world
+    dev = device()
+    buf = torch.zeros((per, max(M, 1)), dtype=torch.float64, device=dev)
+    if local.size:
+        buf[:local.shape[0], :M] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+    if world > 1:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+    else:
+        parts = [buf]
+    parts = [p.cpu().numpy() for p in parts]
+    score = np.full(M, -1e-6, dtype=np.float64)
+    for e in range(E):                               # the reference's order: event 0, 1, 2, ...
+        score = score + parts[e % world][e // world, :M]
+    out = []
+    for m, sc in zip(muts, score):
+        ms = MutationScore()
+        ms.start, ms.orig, ms.mut, ms.score = m.start, m.orig, m.mut, float(sc)
+        out.append(ms)
+    return out
+
+
 def _fresh_region_rand():
     """Every region starts from the random stream of a fresh process — the reference runs one `poreseq consensus`
     process per region file and never seeds rand() (Viterbi.cpp:108) — whichever thread refines it."""

@@ -133,6 +133,17 @@ class PSAlign:
             finally:
                 d.api.muts_destroy(hs)
 
+    def ScoreMutationDeltas(self, muts):
+        """ndarray [events][edits]: what each event adds to each edit's score (MakeMutations.cpp:51); `ScoreMutations` returns
+        -1e-6 plus their sum in event order.  Not part of the reference's surface: the building block of event-sharded scoring
+        (poreseq_amd.dist.score_mutations_event_sharded)."""
+        with PSAlign._Data(self) as d:
+            hm = d.api.muts_create(muts)
+            try:
+                return d.api.score_mutation_deltas(d.h, hm, len(self.events), len(muts))
+            finally:
+                d.api.muts_destroy(hm)
+
     def ApplyMuts(self, pymuts):
         """Greedy MakeMutations over already-scored mutations (pyx:347-375)."""
         with PSAlign._Data(self, point_width=True) as d:

@@ -264,3 +264,40 @@ def test_ranks_on_one_node_split_the_host_cores(monkeypatch):
     finally:
         os.sched_setaffinity(0, before)
         os.environ.pop("PORESEQ_HOST_THREADS", None)
+
+
+WORKER_EVENTS = r'''
+import copy, os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import backends as B
+from poreseq_amd import dist as psdist, synth
+from poreseq_amd.util import DEFAULT_PARAMS
+rank, local, world = psdist.init(backend="gloo")
+P = dict(DEFAULT_PARAMS, verbose=0)
+draft, events, truth = synth.make_region(260, 7, 4242, B.oracle_swalign, P)       # 7 events on 2 ranks: 4 + 3, interleaved
+events[3].ref_align[:] = 0                                                       # an inert event in the middle (adds exactly 0)
+muts = synth.random_point_mutations(np.random.default_rng(9), draft, 150)
+muts[5].start = len(draft) + 3                                                    # past the end: skipped by every event
+pa = B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), P)
+got = psdist.score_mutations_event_sharded(pa, muts)
+want = B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), P).ScoreMutations(muts)
+same = [g.score == w.score and (g.start, g.orig, g.mut) == (w.start, w.orig, w.mut) for g, w in zip(got, want)]
+ok = psdist.max_over_ranks(0.0 if all(same) and len(got) == len(want) else 1.0)
+if rank == 0:
+    print(json.dumps({"world": world, "all_ranks_equal_unsharded": ok == 0.0, "n": len(got), "npos": sum(1 for g in got if g.score > 0)}), flush=True)
+psdist.finalize()
+'''
+
+
+def test_event_sharded_scoring_equals_unsharded_world1_and_world2():
+    """SURVEY 8(e), second axis: the events of one region dealt to the ranks, per-event score terms all-gathered and summed in the
+    reference's event order on every rank — bit-identical to the unsharded ScoreMutations (oracle backend, gloo)"""
+    global WORKER
+    keep, WORKER = WORKER, WORKER_EVENTS
+    try:
+        one, two = run_world(1), run_world(2)
+    finally:
+        WORKER = keep
+    assert one["all_ranks_equal_unsharded"] and two["all_ranks_equal_unsharded"] and two["world"] == 2
+    assert one["n"] == two["n"] == 150 and one["npos"] == two["npos"] > 0

@@ -60,3 +60,30 @@ print(json.dumps({"n": len(res), "lens": [len(r[0]) for r in res], "tmax": psdis
     out = subprocess.check_output([sys.executable, "-c", code], timeout=900, stderr=subprocess.STDOUT)
     r = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
     assert r["n"] == 3 and all(l > 250 for l in r["lens"]) and r["tmax"] == 2.5 and all(s > 0 for s in r["s0"])
+
+
+@pytest.mark.gpu
+def test_hip_event_sharded_scoring_and_deltas():
+    """per-event score terms from the HIP library (ps_score_mutation_deltas): equal to the oracle's, their ordered sum equal to
+    ScoreMutations; the event-sharded driver on one rank (the two-rank exchange runs on gloo in tests/test_dist.py)"""
+    import copy
+    import numpy as np
+    import backends as B
+    from poreseq_amd import dist as psdist, synth
+    from poreseq_amd.poreseqcpp import PSAlign
+    from poreseq_amd.util import DEFAULT_PARAMS
+    P = dict(DEFAULT_PARAMS, verbose=0)
+    draft, events, truth = synth.make_region(700, 6, 4343, B.oracle_swalign, P)
+    events[2].ref_align[:] = 0
+    muts = synth.random_point_mutations(np.random.default_rng(4), draft, 300)
+    muts[7].start = len(draft) + 1
+    mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(events), P)
+    dh, do = mk(PSAlign).ScoreMutationDeltas(muts), mk(B.OraclePSAlign).ScoreMutationDeltas(muts)
+    assert dh.shape == (6, 300) and np.array_equal(dh, do)
+    want = mk(PSAlign).ScoreMutations(muts)
+    s = np.full(300, -1e-6)
+    for e in range(6):
+        s = s + dh[e]
+    assert np.array_equal(s, np.array([w.score for w in want]))
+    got = psdist.score_mutations_event_sharded(mk(PSAlign), muts)
+    assert [g.score for g in got] == [w.score for w in want]

@@ -348,6 +348,36 @@ def test_wide_band_and_many_events_match_oracle():
     assert res[0] == res[1]
 
 
+@pytest.mark.parametrize("width,L", [(45, 400), (150, 900), (430, 1600), (800, 2600)])
+def test_every_strip_height_matches_oracle(width, L):
+    """the strip sweeps' heights K = 4 / 6 / 16 / 32 rows per lane (chosen from the band's widest window; the default width
+    300 -> K = 10 and width 600 -> K = 24 run elsewhere): DP matrices with step codes through the debug hook (forward +
+    backward strip records when the strip sweeps are on), ScoreEvents, ScoreMutations and a Mutate against the oracle"""
+    Pw = dict(P0, realign_width=float(width))
+    draft, events, truth = synth.make_region(L, 4, 300 + width, B.oracle_swalign, Pw)
+    mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(events), Pw)
+    assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents()
+    muts = synth.random_point_mutations(np.random.default_rng(width), draft, 80)
+    assert np.array_equal(scores(mk(PSAlign).ScoreMutations(muts)), scores(mk(B.OraclePSAlign).ScoreMutations(muts)))
+    hip, orc = _capi.load_hip(), B.oracle_api()
+    for d in (0, 1):
+        out = []
+        for api in (hip, orc):
+            h = api.align_create(draft, copy.deepcopy(events), Pw)
+            out.append(api.debug_fill(h, 1, d, events[1].mean.size, len(draft) - 4))
+            api.align_destroy(h)
+        assert np.array_equal(out[0][0], out[1][0], equal_nan=True) and np.array_equal(out[0][1], out[1][1], equal_nan=True), d
+        if d == 0:
+            assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+    res = []
+    for cls in (PSAlign, B.OraclePSAlign):
+        B.reset_rand()
+        pa = mk(cls)
+        res.append((pa.Mutate(reps=2), pa.sequence, [e.ref_like.copy() for e in pa.events]))
+    assert res[0][:2] == res[1][:2]
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+
+
 def test_realign_to_and_copy():
     draft, events, truth = synth.make_region(300, 4, 61, B.oracle_swalign, P0)
     x, y = B.make_pa(PSAlign, draft, copy.deepcopy(events), P0), B.make_pa(B.OraclePSAlign, draft, copy.deepcopy(events), P0)
