@@ -292,12 +292,39 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
                 PS_TRY(rc);
             }
             p_seen = std::max(p_seen, b.P);
+            // per-base likelihood vectors of the chunk's sequences: on the device when every sequence fits k_likes' table (only the
+            // vectors cross PCIe), else from the jobs' ref_align / ref_like on the host
+            std::vector<std::vector<double>> lks(q1 - q0);
+            bool on_device = true;
+            for (size_t q = q0; q < q1; q++) if ((int)need[q].states.size() > likes_max_states()) on_device = false;
+            if (on_device) {
+                std::vector<LikeGroup> groups(q1 - q0);
+                int64_t out_tot = 0;
+                int job = 0;
+                for (size_t q = q0; q < q1; q++) {
+                    LikeGroup& g = groups[q - q0];
+                    const std::string& sd = (*seeds[need[q].r])[need[q].k];
+                    g.job0 = job; g.njobs = as[need[q].r]->E; job += g.njobs;
+                    g.C = (int)need[q].states.size(); g.len = (int)sd.size();
+                    g.out_off = out_tot; out_tot += g.len;
+                }
+                DBuf& gb = rt->buf("like_groups");
+                DBuf& lb = rt->buf("like_out");
+                PS_TRY(gb.ensure(groups.size() * sizeof(LikeGroup)));
+                PS_TRY(lb.ensure((size_t)std::max<int64_t>(out_tot, 1) * sizeof(double)));
+                PS_TRY(rt->up(gb.p, groups.data(), groups.size() * sizeof(LikeGroup)));
+                PS_TRY(launch_likes(rt, b.d, gb.as<LikeGroup>(), (int)groups.size(), lb.as<double>()));
+                double* h_lk = nullptr;
+                PS_TRY(rt->down(&h_lk, lb.p, (size_t)out_tot));
+                PS_HIP(hipStreamSynchronize(rt->stream));
+                tk.lap("seed realign + D2H");
+                for (size_t q = q0; q < q1; q++) lks[q - q0].assign(h_lk + groups[q - q0].out_off, h_lk + groups[q - q0].out_off + groups[q - q0].len);
+            } else {
             double *r_ra = nullptr, *r_rl = nullptr;
             PS_TRY(rt->down(&r_ra, d_ra, nref));
             PS_TRY(rt->down(&r_rl, d_rl, nref));
             PS_HIP(hipStreamSynchronize(rt->stream));
             tk.lap("seed realign + D2H");
-            std::vector<std::vector<double>> lks(q1 - q0);
             par_for((int)(q1 - q0), [&](int qq) {
                 const Need& nd = need[q0 + qq];
                 const Align* a = as[nd.r];
@@ -310,6 +337,7 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
                 }
                 lk.resize(sd.size());
             });
+            }
             for (size_t q = q0; q < q1; q++) as[need[q].r]->seqlikes[(*seeds[need[q].r])[need[q].k]] = std::move(lks[q - q0]);
             rt->stage.release(stage_mark);   // the stream is idle: this batch's staging memory can be reused
             q0 = q1;

@@ -96,6 +96,8 @@ int sweep_prepare(Runtime* rt, Batch& b, int K);  // band / qlo tables + the wid
 int sweep_run(Runtime* rt, Batch& b);             // sweeps, maxima, backtrace, path scores (b.sd.codes placed by the caller)
 void sweep_min_set(int n);                        // forward-only batches of at least n alignments take the strip sweep (< 0: default)
 void sweep2_min_set(int n);                       // the same for Alignment::update batches (sweeps = 2 per alignment)
+int launch_likes(Runtime* rt, const BatchD& b, const LikeGroup* d_groups, int ngroups, double* d_out);   // per-base likelihood vectors on the device
+int likes_max_states();                           // longest sequence (states) k_likes takes
 bool sweep_enabled();                             // PORESEQ_NO_SWEEP unset
 double fwd_job_bytes(const Align* a, int n0, int C);   // device bytes one forward-only alignment job will probably take
 

@@ -202,6 +202,13 @@ struct SweepD {
     int ndir;               // 1: forward-only jobs; 2: sweep job jd = 2 * job + direction
 };
 
+// one sequence's jobs (its events, in order) for the per-base likelihood vector of ScoreAlignments (k_likes, ps_sweep.hip)
+struct LikeGroup {
+    int job0, njobs;        // the sequence's jobs inside the batch
+    int C, len;             // states of the sequence; doubles of its vector (bases)
+    int64_t out_off;        // into the output pool
+};
+
 // ---- kernel launchers (ps_kernels.hip) ------------------------------------------------------
 int launch_updaterefs(Runtime* rt, const BatchD& b);
 int launch_lb(Runtime* rt, const BatchD& b, int which /*0: lb_off, 1: lbn_off*/, int maxlbn);

@@ -471,6 +471,57 @@ __global__ __launch_bounds__(64) void k_like_b(BatchD b) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The `likes` loop of ScoreAlignments (cpp/MakeMutations.cpp:168-189) on the device: per (sequence, event) the per-base cumulative
+// likelihood is piecewise constant — likes[k + 1] += ref_like of the LAST level aligned at or before base k (0 before the first) —
+// and a sequence's vector is the sum of its events' in event order.  One 256-thread block per sequence (group of E jobs): for
+// each event in order, every aligned level marks its base with its index (atomic max: the last level of equal bases wins), a
+// prefix maximum over the bases turns the marks into "last aligned level so far", and the block adds ref_like of that level to the
+// vector — the same additions in the same order as the host loop, so only L doubles per sequence cross PCIe instead of every
+// job's ref_align / ref_like (517 MB per FindMutations call of a 20-region batch).
+// ------------------------------------------------------------------------------------------------
+constexpr int LK_MAXC = 12 * 1024;      // bases per sequence the LDS index table holds (longer sequences take the host loop)
+__global__ __launch_bounds__(256) void k_likes(BatchD b, const LikeGroup* __restrict__ groups, double* __restrict__ out) {
+    __shared__ int s_idx[LK_MAXC];
+    __shared__ int s_part[256];
+    const LikeGroup G = groups[blockIdx.x];
+    const int tid = threadIdx.x, nk = G.C + 4;                    // bases k = 0 .. C + 3
+    double* __restrict__ lk = out + G.out_off;
+    const int chunk = (nk + 255) / 256, k0 = min(nk, tid * chunk), k1 = min(nk, k0 + chunk);
+    for (int k = tid; k < G.len; k += 256) lk[k] = 0.0;
+    for (int e = 0; e < G.njobs; e++) {
+        const JobD& J = b.jobs[G.job0 + e];
+        const double* __restrict__ ra = J.ra;
+        const double* __restrict__ rl = J.rl;
+        for (int k = tid; k < nk; k += 256) s_idx[k] = -1;
+        __syncthreads();
+        for (int t = tid; t < J.n0; t += 256) {
+            const double a = ra[t];
+            if (a > 0) { const int k = (int)a; if (k < nk) atomicMax(&s_idx[k], t); }
+        }
+        __syncthreads();
+        int run = -1;                                                 // prefix maximum: chunk-local, then across the chunks
+        for (int k = k0; k < k1; k++) { run = max(run, s_idx[k]); s_idx[k] = run; }
+        s_part[tid] = run;
+        __syncthreads();
+        int before = -1;
+        for (int q = 0; q < tid; q++) before = max(before, s_part[q]);
+        for (int k = k0; k < k1; k++) {
+            const int t = max(s_idx[k], before);
+            if (k >= 1 && k < G.C + 3 && k + 1 < G.len) lk[k + 1] += t >= 0 ? rl[t] : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_likes(Runtime* rt, const BatchD& b, const LikeGroup* d_groups, int ngroups, double* d_out) {
+    if (!ngroups) return PS_OK;
+    hipLaunchKernelGGL(k_likes, dim3(ngroups), dim3(256), 0, rt->stream, b, d_groups, d_out);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+int likes_max_states() { return LK_MAXC - 4; }
+
 // =================================================================================================
 // host side
 // =================================================================================================

@@ -9,7 +9,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$TAG -o r -- pyt
 grep '^{' /tmp/pb_$TAG.log | tail -1 | cut -c1-160
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof
 cp $(find /tmp/pb_$TAG -name '*kernel_stats.csv' | head -1) $GRAFT_REPO_ROOT/gpurun_out/prof/${TAG}_kernel_stats.csv
-cut -d, -f8-12,14- $(find /tmp/pb_$TAG -name '*kernel_trace.csv' | head -1) | gzip > $GRAFT_REPO_ROOT/gpurun_out/prof/${TAG}_trace.csv.gz   # (queue, kernel, times, grid: for offline timelines)
+python3 - $(find /tmp/pb_$TAG -name '*kernel_trace.csv' | head -1) $GRAFT_REPO_ROOT/gpurun_out/prof/${TAG}_trace.csv.gz <<'PY'   # (queue, kernel, times, workgroups: for offline timelines)
+import csv, gzip, sys
+w = gzip.open(sys.argv[2], "wt")
+for r in csv.DictReader(open(sys.argv[1])):
+    w.write("%s,%s,%s,%s,%d\n" % (r["Queue_Id"], r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ps::", "").replace(",", ";"), r["Start_Timestamp"], r["End_Timestamp"],
+                                  int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)))
+w.close()
+PY
 python3 - $(find /tmp/pb_$TAG -name '*kernel_trace.csv' | head -1) /tmp/pb_$TAG.log <<'PY'
 import csv, sys, json, collections
 rows = []
