@@ -130,7 +130,7 @@ def main():
     params = dict(DEFAULT_PARAMS, verbose=0)
     api = _capi.load_hip()
     if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))   # (ranks that outnumber the devices share them: tests)
 
     def make(seed, length=None):
         return synth.make_region(length or args.length, args.events, seed, swalign, params)

@@ -20,9 +20,9 @@ def init(backend=None):
     force = os.environ.get("PORESEQ_FORCE_PG") == "1"     # tests: exercise the collective path on one GPU
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("PORESEQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29531")

@@ -62,6 +62,22 @@ print(json.dumps({"n": len(res), "lens": [len(r[0]) for r in res], "tmax": psdis
     assert r["n"] == 3 and all(l > 250 for l in r["lens"]) and r["tmax"] == 2.5 and all(s > 0 for s in r["s0"])
 
 
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """bench.py's N > 1 path end to end — barrier, max over ranks, whole-job value, core pinning, process-group tear-down — with two
+    ranks on the one GPU of the test box (gloo instead of RCCL, which refuses two ranks per device; no data-path collective is involved)"""
+    env = dict(os.environ, PORESEQ_DIST_BACKEND="gloo")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29519", os.path.join(B.ROOT, "bench.py"),
+                                   "--gpus", "2", "--steps", "1", "--warmup", "0", "--length", "1000", "--regions-per-gpu", "6",
+                                   "--batches-in-flight", "2", "--no-cpu", "--no-extras"],
+                                  env=env, timeout=900, stderr=subprocess.STDOUT)
+    line = [l for l in out.decode().splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert abs(r["value"] - 2 * 6 * 1.0 / (r["ms_per_step"] / 1e3)) < 1e-6 * r["value"]      # whole-job rate over the slowest rank's time
+    assert r["resident"]["value"] >= r["value"]
+
+
 @pytest.mark.gpu
 def test_hip_event_sharded_scoring_and_deltas():
     """per-event score terms from the HIP library (ps_score_mutation_deltas): equal to the oracle's, their ordered sum equal to
