@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--batches-in-flight", type=int, default=7,
                     help="lock-step batches per GPU (one host thread each): while one batch is in a thin phase or on the host, "
                          "the others keep the GPU full; the regions of a step are dealt round-robin to the batches")
+    ap.add_argument("--stream", action="store_true",
+                    help="let the timed steps' batches stream through the slots (default: every step finishes before the next one's batches "
+                         "start; measured the same on one MI355X: 141.1 against 140.5 kb/s)")
     ap.add_argument("--cpu-length", type=int, default=1000, help="region length of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip everything that touches the CPU checkers (oracle / reference)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-region, 1 kb and profiled passes (profiling runs)")
@@ -140,69 +143,108 @@ def main():
         pa.sequence, pa.events, pa.params = region[0], copy.deepcopy(region[1]), dict(params)
         return pa
 
-    live_prof = []   # per timed step: {class: [ms, launches, bytes, units]} summed over the step's host threads
+    live_prof = []      # per timed run: {class: [ms, launches, bytes, units]} summed over the slots
+    batch_done_s = []   # per timed run: when each lock-step batch finished, seconds after the clock started
+    load_s = []         # per timed run: seconds the slots spent marshalling + copying events to the device (inside the clock), / slots
 
-    load_s = []      # per timed step: seconds of the step spent marshalling + copying the events to the device (inside the clock)
+    # Batch slots: NB host threads that live for the whole run (each owns a library runtime: stream + device pools).  A run hands
+    # them the lock-step batches of one or more steps through a queue; a slot takes the next batch when its own is done — the
+    # production shape (poreseq_amd.dist.refine_regions(in_flight=NB)): regions stream through the slots, there is no barrier
+    # between the batches of consecutive steps with --stream (the default finishes every step first).
+    import queue
+    import threading
+    NB = max(1, args.batches_in_flight)
+    jobs = queue.Queue()
+    errs = []
 
-    def run_batch(regs, timed=False, nb=1):
-        """one step: the regions dealt to `nb` lock-step batches, one host thread each; the clock (when timed) starts BEFORE
-        the events are marshalled and copied to the device"""
-        import threading
-        nb = max(1, min(nb, len(regs)))
-        groups = [regs[k::nb] for k in range(nb)]
-        pas = [[as_pa(r) for r in g] for g in groups]
-        rbs = [RegionBatch(p) for p in pas]
-        outs = [None] * nb
-        errs = []
-
-        def load(k):
+    def slot_main():
+        while True:
+            fn = jobs.get()
             try:
-                rbs[k].load()
+                if fn is None:
+                    return
+                fn()
             except Exception as e:   # pragma: no cover
                 errs.append(e)
+            finally:
+                jobs.task_done()
 
-        profs = [None] * nb
+    slots = [threading.Thread(target=slot_main, daemon=True) for _ in range(NB)]
+    for t in slots:
+        t.start()
 
-        def work(k):
-            try:
-                if timed:            # HIP events around every hot-kernel launch on this thread's stream, read after the work
-                    api.prof_reset()
-                    api.prof_enable(2)
-                outs[k] = consensus_regions(pas[k], params, batch=rbs[k])
-                if timed:
-                    profs[k] = {c: list(api.prof_get(c)) + [api.prof_units(c)] for c in KERNEL_OF}
-                    api.prof_enable(0)
-            except Exception as e:   # pragma: no cover
-                errs.append(e)
+    def on_every_slot(fn):
+        """fn() once in each slot thread (per-thread profiling state lives in the library's thread-local runtime)"""
+        gate = threading.Barrier(NB)
+        for _ in range(NB):
+            jobs.put(lambda: (gate.wait(), fn()))
+        jobs.join()
 
-        def fan(fn):
-            th = [threading.Thread(target=fn, args=(k,)) for k in range(1, nb)]
-            for t in th:
-                t.start()
-            fn(0)
-            for t in th:
-                t.join()
-            if errs:
-                raise errs[0]
+    def in_slot(fn):
+        """fn() in one of the slot threads: the main thread never enters the library, so the device is shared by NB runtimes"""
+        box = []
+        jobs.put(lambda: box.append(fn()))
+        jobs.join()
+        if errs:
+            raise errs[0]
+        return box[0]
 
+    def run_steps(step_regs, timed=False, nb=NB):
+        """the batches of the given steps (each step's regions dealt round-robin to `nb` lock-step batches) through the slots;
+        the clock (when timed) starts BEFORE any batch's events are marshalled and copied to the device.
+        Returns (seconds, [per step: results in region order])."""
+        items = []
+        for si, regs in enumerate(step_regs):
+            n = max(1, min(nb, len(regs)))
+            for k in range(n):
+                pas = [as_pa(r) for r in regs[k::n]]
+                items.append({"step": si, "k": k, "n": n, "pas": pas, "rb": RegionBatch(pas), "out": None, "done": 0.0, "load": 0.0})
+        profs = []
+        plock = threading.Lock()
         if timed:
+            on_every_slot(lambda: (api.prof_reset(), api.prof_enable(2)))   # HIP events around every hot-kernel launch, read after the work
             psdist.barrier()
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
         t0 = time.perf_counter()
-        fan(load)           # each thread creates its own batch's AlignData: the library's runtimes are per host thread
-        t1 = time.perf_counter()
-        fan(work)
+
+        def work(it):
+            t = time.perf_counter()
+            it["rb"].load()          # marshalling + H2D of the batch's events
+            it["load"] = time.perf_counter() - t
+            it["out"] = consensus_regions(it["pas"], params, batch=it["rb"])
+            it["done"] = time.perf_counter() - t0
+
+        for it in items:
+            jobs.put(lambda it=it: work(it))
+        jobs.join()
         if timed and torch.cuda.is_available():
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if errs:
+            raise errs[0]
         if timed:
-            load_s.append(t1 - t0)
-            live_prof.append({c: [sum(p[c][i] for p in profs if p) for i in range(4)] for c in KERNEL_OF})
-        out = [None] * len(regs)
-        for k in range(nb):
-            out[k::nb] = outs[k]
-        return dt, out
+            def collect():
+                p = {c: list(api.prof_get(c)) + [api.prof_units(c)] for c in KERNEL_OF}
+                api.prof_enable(0)
+                with plock:
+                    profs.append(p)
+            on_every_slot(collect)
+            batch_done_s.append(sorted(round(it["done"], 3) for it in items))
+            load_s.append(sum(it["load"] for it in items) / NB)
+            live_prof.append({c: [sum(p[c][i] for p in profs) for i in range(4)] for c in KERNEL_OF})
+        outs = []
+        for si, regs in enumerate(step_regs):
+            out = [None] * len(regs)
+            for it in items:
+                if it["step"] == si:
+                    out[it["k"]::it["n"]] = it["out"]
+            outs.append(out)
+        return dt, outs
+
+    def run_batch(regs, nb=1):
+        dt, outs = run_steps([regs], nb=nb)
+        return dt, outs[0]
 
     # synthetic inputs for every step of this rank, generated outside the timed region
     R = max(1, args.regions_per_gpu)
@@ -210,7 +252,7 @@ def main():
     # (at most three distinct sets: generating 25 x 64 regions would take longer than refining them; later steps go round the sets —
     #  every step recomputes everything, nothing is cached between steps)
     nsets = min(nsteps, 3)
-    sets = [[make(1002 + 100000 * rank + 1000 * k + s) for k in range(R)] for s in range(nsets)]
+    sets = in_slot(lambda: [[make(1002 + 100000 * rank + 1000 * k + s) for k in range(R)] for s in range(nsets)])
     regions = [sets[s % nsets] for s in range(nsteps)]
 
     pre = {}
@@ -221,7 +263,7 @@ def main():
         pre["single_region_s"] = lone[len(lone) // 2]
         pre["single_region_s_all"] = lone
         # ---- north star comparison point: 1 kb / 10x ----
-        k1 = [make(5000 + k, 1000) for k in range(64)]
+        k1 = in_slot(lambda: [make(5000 + k, 1000) for k in range(64)])
         run_batch(k1[:1])
         t1 = min(run_batch(k1[:1])[0] for _ in range(3))
         run_batch(k1)
@@ -230,14 +272,19 @@ def main():
                                  "single_region_kb_s": 1.0 / t1, "lock_step_regions": len(k1),
                                  "lock_step_kb_s": len(k1) * 1.0 / tb}
 
-    NB = max(1, args.batches_in_flight)
-    for s in range(args.warmup):
-        run_batch(regions[s], nb=NB)
-    dt = 0.0
-    last = None
-    for s in range(args.warmup, nsteps):
-        t, last = run_batch(regions[s], timed=True, nb=NB)
-        dt += t
+    run_steps([regions[s] for s in range(args.warmup)])
+    timed_regs = [regions[s] for s in range(args.warmup, nsteps)]
+    if os.environ.get("PORESEQ_TRACE"):
+        sys.stderr.write("=== MEASURED RUN ===\n")       # tools/tracesum.py sums the host phases after this line
+    if not args.stream:
+        dt, last = 0.0, None
+        for regs in timed_regs:
+            t, outs = run_steps([regs], timed=True)
+            dt += t
+            last = outs[-1]
+    else:
+        dt, outs = run_steps(timed_regs, timed=True)
+        last = outs[-1]
     psdist.barrier()
     dt_res = psdist.max_over_ranks(dt - sum(load_s))
     dt = psdist.max_over_ranks(dt)
@@ -249,20 +296,24 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / max(args.steps, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "poreseq consensus, %d kb region, %dx synthetic coverage (BASELINE configs[1]), full Mutate.py "
-                               "schedule per region; a step is %d independent regions per GPU, refined as %d lock-step batches; "
-                               "marshalling + H2D of the events, host greedy steps and D2H inside the clock"
-                               % (args.length // 1000, args.events, R, NB),
-                   "region_bases": args.length, "events": args.events, "regions_per_gpu": R, "batches_in_flight": NB,
+                               "schedule per region; a step is %d independent regions per GPU = %d lock-step batches; the batches of the timed "
+                               "steps %s through %d batch slots (host threads) per GPU; marshalling + H2D of the events, host greedy "
+                               "steps and D2H inside the clock"
+                               % (args.length // 1000, args.events, R, NB,
+                                  "run step by step (a step's batches all finish before the next step's start)" if not args.stream
+                                  else "stream (a slot takes the next batch when its own is done; no barrier between steps)", NB),
+                   "region_bases": args.length, "events": args.events, "regions_per_gpu": R, "batches_in_flight": NB, "step_barrier": not args.stream,
                    "parallelism": "%d regions x %d GPU(s), %d host thread(s) per GPU, no data-path collective" % (R, world, NB)},
     }
 
     out["resident"] = {"value": world * R * kb * args.steps / dt_res, "unit": "kb/s", "ms_per_step": 1000.0 * dt_res / max(args.steps, 1),
                        "load_ms_per_step": 1000.0 * sum(load_s) / max(args.steps, 1),
-                       "note": "the same steps with the events' marshalling + H2D left out of the clock (not the metric's definition)"}
+                       "note": "estimate: the clock minus the slots' average marshalling + H2D time (loads overlap other slots' work; not the metric's definition)"}
 
+    out["batch_done_s"] = batch_done_s
     if rank == 0:
-        a0 = swalign(regions[-1][0][0], regions[-1][0][2])[0]
-        a1 = swalign(last[0][0], regions[-1][0][2])[0]
+        a0 = in_slot(lambda: swalign(regions[-1][0][0], regions[-1][0][2])[0])
+        a1 = in_slot(lambda: swalign(last[0][0], regions[-1][0][2])[0])
         out["accuracy"] = {"draft_percent": a0, "consensus_percent": a1}
         out.update(pre)
 
@@ -297,11 +348,14 @@ def main():
             if not args.no_extras:
                 # the same kernel class with the chip to itself: one lock-step batch of the timed size, alone, event pair read after
                 # every launch (the kernel's own quality; the figures above include what a launch shares the chip with)
-                api.prof_reset()
-                api.prof_enable(1)
-                run_batch(regions[-1][:max(1, R // NB)])
-                api.prof_enable(0)
-                ims, il, ib = api.prof_get(dom)
+                def alone():
+                    pas = [as_pa(r) for r in regions[-1][:max(1, R // NB)]]
+                    api.prof_reset()
+                    api.prof_enable(1)
+                    consensus_regions(pas, params)
+                    api.prof_enable(0)
+                    return api.prof_get(dom)
+                ims, il, ib = in_slot(alone)
                 if ims > 0:
                     roof["one_batch_alone"] = {"avg_launch_ms": ims / max(il, 1), "alg_bytes_per_launch": ib / max(il, 1),
                                                "achieved": (ib / 1e9) / (ims / 1e3), "frac": (ib / 1e9) / (ims / 1e3) / HBM_PEAK_GBS,
@@ -334,9 +388,9 @@ def main():
             cls = B.RefPSAlign if use_ref else B.OraclePSAlign
             cpu_sw = B.ref_swalign if use_ref else B.oracle_swalign
             d, ev, tr = synth.make_region(400, 6, 77, cpu_sw, params)
-            g = B.make_pa(PSAlign, d, copy.deepcopy(ev), params).ScoreEvents()
+            g = in_slot(lambda: B.make_pa(PSAlign, d, copy.deepcopy(ev), params).ScoreEvents())
             c = B.make_pa(cls, d, copy.deepcopy(ev), params).ScoreEvents()
-            gp = B.make_pa(PSAlign, d, copy.deepcopy(ev), params).ScorePoints()
+            gp = in_slot(lambda: B.make_pa(PSAlign, d, copy.deepcopy(ev), params).ScorePoints())
             cp = B.make_pa(cls, d, copy.deepcopy(ev), params).ScorePoints()
             out["logl_max_rel_err_vs_cpu"] = max([abs(x - y) / max(abs(y), 1e-300) for x, y in zip(g, c)] +
                                                  [abs(x.score - y.score) / abs(y.score) for x, y in zip(gp, cp) if abs(y.score) > 1e-3])

@@ -213,20 +213,38 @@ def run_regions(regions, process, max_events=64, in_flight=1, fresh_rand=_fresh_
     return gather_regions(local, len(regions), max_events)
 
 
-def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_events=64):
+def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_events=64, in_flight=1):
     """Consensus for a list of (start, end) regions on all ranks: regions are dealt longest-first to the ranks
     (`shard` with weights), each rank refines its share in lock-step batches of `batch` regions on its GPU
-    (poreseq_amd.batch), and every rank receives every region's result.  Returns [(sequence, accuracy)] in region order."""
+    (poreseq_amd.batch), and every rank receives every region's result.  Returns [(sequence, accuracy)] in region order.
+
+    in_flight > 1 keeps that many lock-step batches on the GPU at once, one host thread (slot) each — the library gives every
+    thread its own stream and device pools, and a slot takes the next batch when its own is done, so a rank's regions stream
+    through the slots (bench.py: 7 slots of 20 regions on one MI355X).  Every region draws from its own random stream
+    (poreseq_amd.batch), so the results do not depend on batch, in_flight or on which slot refines a region."""
     from .consensus import consensus_regions
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     mine = shard(regions, rank, world, weights=[b - a for a, b in regions])
-    local = []
-    for k in range(0, len(mine), max(1, int(batch))):
-        chunk = mine[k:k + max(1, int(batch))]
+    step = max(1, int(batch))
+    chunks = [mine[k:k + step] for k in range(0, len(mine), step)]
+
+    def one(chunk):
         pas = [make_region_pa(a, b) for _, (a, b) in chunk]
         res = consensus_regions(pas, params, reps=reps)
-        for (idx, _), (seq, acc) in zip(chunk, res):
-            local.append((idx, seq, np.array([acc])))
+        return [(idx, seq, np.array([acc])) for (idx, _), (seq, acc) in zip(chunk, res)]
+
+    local = [r for part in stream_batches(chunks, one, in_flight) for r in part]
     got = gather_regions(local, len(regions), max_events)
     return [(s, float(c[0])) for s, c in got]
+
+
+def stream_batches(items, work, in_flight=1):
+    """work(item) for every item on up to `in_flight` host threads; a thread takes the next item when its own is done.
+    Results in item order; the first exception is re-raised after the running items have finished."""
+    items = list(items)
+    if in_flight <= 1 or len(items) <= 1:
+        return [work(it) for it in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=int(in_flight)) as pool:
+        return list(pool.map(work, items))

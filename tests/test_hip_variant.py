@@ -200,3 +200,24 @@ def test_second_streams_on_priority_levels_finish_and_match():
     want = run({})
     assert run({"PORESEQ_FORCE_STREAM2": "prio"}) == want
     assert run({"PORESEQ_FORCE_STREAM2": "1", "PORESEQ_ONE_PRIORITY": "1"}) == want
+
+
+def test_refine_regions_batch_slots_in_flight_equal_one_batch_at_a_time():
+    """poreseq_amd.dist.refine_regions(in_flight=N): lock-step batches streaming through N host-thread slots (bench.py's shape) give
+    every region the result of batches refined one after the other — whichever slot takes a batch, whatever else shares the GPU."""
+    from poreseq_amd import dist as psdist
+    regions = [(1000 * k, 1000 * k + 420 + 30 * (k % 3)) for k in range(9)]
+    made = {r: synth.make_region(r[1] - r[0], 6, 700 + r[0] // 1000, B.oracle_swalign, P0) for r in regions}
+
+    def make(a, b):
+        d, e, _t = made[(a, b)]
+        return B.make_pa(PSAlign, d, copy.deepcopy(e), P0)
+
+    one = psdist.refine_regions(regions, make, params=P0, batch=2)
+    many = psdist.refine_regions(regions, make, params=P0, batch=2, in_flight=3)
+    assert one == many and len(one) == len(regions)
+    # and the oracle, region by region in a fresh process's random stream, says the same for the first two
+    for r, (seq, acc) in list(zip(regions, one))[:2]:
+        B.reset_rand()
+        d, e, _t = made[r]
+        assert consensus_region(B.make_pa(B.OraclePSAlign, d, copy.deepcopy(e), P0), P0) == (seq, acc)

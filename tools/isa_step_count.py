@@ -7,7 +7,7 @@ import collections, re, sys
 
 src = open(sys.argv[1]).read().splitlines()
 want = sys.argv[2] if len(sys.argv) > 2 else "k_fillILi768ELb1ELb1"
-start = next(i for i, l in enumerate(src) if l.startswith("_ZN2ps6") and want in l and ": ; @" in l)
+start = next(i for i, l in enumerate(src) if l.startswith("_ZN2ps") and want in l and ": ; @" in l)
 end = next(i for i in range(start, len(src)) if "s_endpgm" in src[i])
 body = src[start:end]
 
