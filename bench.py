@@ -169,16 +169,23 @@ def main():
             finally:
                 jobs.task_done()
 
-    slots = [threading.Thread(target=slot_main, daemon=True) for _ in range(NB)]
-    for t in slots:
-        t.start()
+    slots = []
+
+    def start_slots(n):
+        """(the single-region passes run with ONE slot alive: a thread alone inside the library gets the whole device and a second
+        stream for its Smith-Waterman batches; the other slots start before the warm-up steps)"""
+        while len(slots) < n:
+            slots.append(threading.Thread(target=slot_main, daemon=True))
+            slots[-1].start()
 
     def on_every_slot(fn):
         """fn() once in each slot thread (per-thread profiling state lives in the library's thread-local runtime)"""
-        gate = threading.Barrier(NB)
-        for _ in range(NB):
+        gate = threading.Barrier(len(slots))
+        for _ in range(len(slots)):
             jobs.put(lambda: (gate.wait(), fn()))
         jobs.join()
+
+    start_slots(1)
 
     def in_slot(fn):
         """fn() in one of the slot threads: the main thread never enters the library, so the device is shared by NB runtimes"""
@@ -272,6 +279,7 @@ def main():
                                  "single_region_kb_s": 1.0 / t1, "lock_step_regions": len(k1),
                                  "lock_step_kb_s": len(k1) * 1.0 / tb}
 
+    start_slots(NB)
     run_steps([regions[s] for s in range(args.warmup)])
     timed_regs = [regions[s] for s in range(args.warmup, nsteps)]
     if os.environ.get("PORESEQ_TRACE"):
