@@ -213,14 +213,19 @@ int runtime(Runtime** out) {
             // overlap with the base realign inside FindMutations) is created on first use (second_stream()).
             // Partitioning the CUs between them (hipExtStreamCreateWithCUMask) was measured and made no
             // difference, so it is not used.
-            // The runtimes' streams are dealt round-robin to the device's stream priority levels (three on MI355X).  Not for the
-            // priorities' sake: HIP keeps a separate set of hardware queues per level (four each by default), and streams that share
-            // a hardware queue run their kernels one after the other.  Seven lock-step batches on one level = seven streams on four
-            // queues, three kernels in flight on average and 108 kb/s; over three levels every stream has a queue of its own: 121 kb/s.
-            // (PORESEQ_ONE_PRIORITY=1: all streams on the default level.)
+            // Streams and hardware queues.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per stream
+            // priority level (default 4), and streams that share a queue run their kernels one after the other: seven lock-step
+            // batches on one level = seven streams on four queues, three kernels in flight on average, 108 kb/s.
+            //  * GPU_MAX_HW_QUEUES >= 8 in the environment (the poreseq_amd package sets 8 when it is imported before the HIP runtime
+            //    starts; C callers export it themselves): every runtime's stream on the default level, a queue each — 146-147 kb/s.
+            //  * otherwise the streams are dealt round-robin to the device's three priority levels, not for the priorities' sake but
+            //    for the 3 x 4 queues: 141 kb/s — the two or three batches on the lowest level finish ~0.8 s after the others
+            //    (profiles/r03_d_sweep_forms.md).
+            // (PORESEQ_ONE_PRIORITY=1 forces the default level, PORESEQ_PRIORITY_LEVELS=1 the dealing.)
             auto make_stream = [&](hipStream_t* st) {
                 static std::atomic<int> seq(0);
-                static const bool one = getenv("PORESEQ_ONE_PRIORITY") != nullptr;
+                static const bool one = getenv("PORESEQ_ONE_PRIORITY") != nullptr ||
+                                        (!getenv("PORESEQ_PRIORITY_LEVELS") && getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) >= 8);
                 int lo = 0, hi = 0;
                 if (!one && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo > hi)
                     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi + seq++ % (lo - hi + 1));
