@@ -280,6 +280,7 @@ def main():
                                  "lock_step_kb_s": len(k1) * 1.0 / tb}
 
     start_slots(NB)
+    on_every_slot(api.prof_reset)     # every slot owns its runtime before the first batch sizes its pools: the device is shared NB ways from the start
     run_steps([regions[s] for s in range(args.warmup)])
     timed_regs = [regions[s] for s in range(args.warmup, nsteps)]
     if os.environ.get("PORESEQ_TRACE"):

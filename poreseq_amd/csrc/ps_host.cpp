@@ -56,7 +56,12 @@ int DBuf::ensure(size_t bytes) {
             p = nullptr;
             e = got ? hipMalloc(&p, want) : e;
         }
-        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(PS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); 
+            size_t fr = 0, tt = 0;
+            (void)hipMemGetInfo(&fr, &tt);
+            return fail(PS_ERR_NOMEM, std::string("hipMalloc of ") + std::to_string(want >> 20) + " MB: " + hipGetErrorString(e) + " (" + std::to_string(fr >> 20) + " of " +
+                                      std::to_string(tt >> 20) + " MB free, " + std::to_string((long long)(g_pool_bytes.load() >> 20)) + " MB in this process's pools)");
+        }
     }
     cap = want;
     g_pool_bytes += (long long)cap;
@@ -418,7 +423,10 @@ double device_share_bytes() {
         if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 48e9;
         dev_total.store(tot);
     }
-    return std::max(2e9, 0.65 * (double)tot / std::max(4, peak_runtimes()));
+    // (every runtime also holds ~4 % of an MI355X outside the matrix pools at 10 kb x 20 regions — Viterbi tables, Smith-Waterman
+    //  checkpoints, band tables: beyond seven runtimes the matrix fraction gives way)
+    const int nrt = std::max(4, peak_runtimes());
+    return std::max(2e9, std::min(0.65, 0.95 - 0.04 * nrt) * (double)tot / nrt);
 }
 
 // The DP matrices ("rec": 16-byte records, or a strip sweep's step codes, which alias it; "flg": step words) are the only big pools,

@@ -245,6 +245,21 @@ def stream_batches(items, work, in_flight=1):
     items = list(items)
     if in_flight <= 1 or len(items) <= 1:
         return [work(it) for it in items]
+    import threading
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=int(in_flight)) as pool:
+    n = min(int(in_flight), len(items))
+    gate = threading.Barrier(n)
+
+    def enter(_):
+        # every worker enters the library before the first batch sizes its device pools: the device is shared n ways from the start
+        # (a runtime that sized its pools while it was alone would hold twice its share)
+        try:
+            from . import _capi
+            _capi.load_hip().prof_reset()
+        except Exception:   # (a driver over another backend: the hint is moot, the work itself reports what is wrong)
+            pass
+        gate.wait()
+
+    with ThreadPoolExecutor(max_workers=n) as pool:
+        list(pool.map(enter, range(n)))
         return list(pool.map(work, items))
