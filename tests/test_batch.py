@@ -5,6 +5,7 @@ driver over the oracle's (looping) batch entry points.  GPU: the HIP library's b
 run region by region, and against the library's own single-region path at a size the oracle cannot reach in a test.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -129,3 +130,13 @@ def test_hip_seed_chunks_are_cut_again_when_the_bands_are_wider_than_guessed():
     got2, err2 = run({"PORESEQ_MAX_BATCH_GB": "0.002"})
     assert "the rest in chunks" in err2  # Smith-Waterman batches larger than an eighth of the share
     assert got2 == want
+
+
+def test_package_import_asks_hip_for_eight_hardware_queues_unless_told_otherwise():
+    """poreseq_amd/__init__.py: GPU_MAX_HW_QUEUES=8 is set at import when nobody has set it (lock-step batches in flight want a hardware
+    queue each: DESIGN.md 5b); a value from the user's environment stays."""
+    import subprocess, sys
+    code = "import os, sys; sys.path.insert(0, %r); import poreseq_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % B.ROOT
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, timeout=300).decode().split()[-1] == "8"
+    assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="4"), timeout=300).decode().split()[-1] == "4"
