@@ -23,7 +23,7 @@ def _want_hw_queues():
             return
     except Exception:   # pragma: no cover
         return
-    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    _os.environ["GPU_MAX_HW_QUEUES"] = "12"
 
 
 _want_hw_queues()

@@ -221,7 +221,7 @@ int runtime(Runtime** out) {
             // Streams and hardware queues.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per stream
             // priority level (default 4), and streams that share a queue run their kernels one after the other: seven lock-step
             // batches on one level = seven streams on four queues, three kernels in flight on average, 108 kb/s.
-            //  * GPU_MAX_HW_QUEUES >= 8 in the environment (the poreseq_amd package sets 8 when it is imported before the HIP runtime
+            //  * GPU_MAX_HW_QUEUES >= 8 in the environment (the poreseq_amd package sets 12 when it is imported before the HIP runtime
             //    starts; C callers export it themselves): every runtime's stream on the default level, a queue each — 146-147 kb/s.
             //  * otherwise the streams are dealt round-robin to the device's three priority levels, not for the priorities' sake but
             //    for the 3 x 4 queues: 141 kb/s — the two or three batches on the lowest level finish ~0.8 s after the others

@@ -132,11 +132,11 @@ def test_hip_seed_chunks_are_cut_again_when_the_bands_are_wider_than_guessed():
     assert got2 == want
 
 
-def test_package_import_asks_hip_for_eight_hardware_queues_unless_told_otherwise():
-    """poreseq_amd/__init__.py: GPU_MAX_HW_QUEUES=8 is set at import when nobody has set it (lock-step batches in flight want a hardware
+def test_package_import_asks_hip_for_more_hardware_queues_unless_told_otherwise():
+    """poreseq_amd/__init__.py: GPU_MAX_HW_QUEUES=12 is set at import when nobody has set it (lock-step batches in flight want a hardware
     queue each: DESIGN.md 5b); a value from the user's environment stays."""
     import subprocess, sys
     code = "import os, sys; sys.path.insert(0, %r); import poreseq_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % B.ROOT
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.check_output([sys.executable, "-c", code], env=env, timeout=300).decode().split()[-1] == "8"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, timeout=300).decode().split()[-1] == "12"
     assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="4"), timeout=300).decode().split()[-1] == "4"
