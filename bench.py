@@ -439,6 +439,10 @@ def main():
                 pass
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
+    for _ in slots:          # the slot threads leave (and hand their runtimes back) before the process group goes
+        jobs.put(None)
+    for t in slots:
+        t.join()
     psdist.finalize()
 
 
