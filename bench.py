@@ -320,6 +320,9 @@ def main():
                        "note": "estimate: the clock minus the slots' average marshalling + H2D time (loads overlap other slots' work; not the metric's definition)"}
 
     out["batch_done_s"] = batch_done_s
+    if torch.cuda.is_available():   # the slots' pools only grow: what is free now is the headroom the steps ran with
+        fr, tt = torch.cuda.mem_get_info()
+        out["device_memory"] = {"total_gb": tt / 1e9, "free_gb_after_timed_steps": fr / 1e9}
     if rank == 0:
         a0 = in_slot(lambda: swalign(regions[-1][0][0], regions[-1][0][2])[0])
         a1 = in_slot(lambda: swalign(last[0][0], regions[-1][0][2])[0])
