@@ -429,10 +429,14 @@ int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, in
     PS_TRY(rt->buf("vit_regs").ensure(R * sizeof(VitReg)));
     PS_TRY(rt->buf("vit_posreg").ensure((size_t)ttot * sizeof(int)));
     PS_TRY(rt->buf("vit_in").ensure((size_t)std::max<int64_t>(intot, 1) * sizeof(double)));
-    PS_TRY(rt->buf("vit_obs").ensure((size_t)ttot * NS * sizeof(double)));
-    PS_TRY(rt->buf("vit_eobs").ensure((size_t)ttot * NS * sizeof(double)));
-    PS_TRY(rt->buf("vit_bp").ensure((size_t)ttot * NS * sizeof(short)));
-    PS_TRY(rt->buf("vit_fwd").ensure((size_t)(nkeep ? ttot : 1) * NS * sizeof(double)));
+    // The position x state tables (8 KB per position and table: 5.3 GB for 20 regions of 10 kb) live in the score-matrix pool: no
+    // alignment is in flight during a ViterbiMutate call, and a runtime that kept them beside the matrices would hold ~2 % of an
+    // MI355X for a phase that is 4 % of a schedule (seven runtimes: 38 GB that the matrices of the other phases can use).
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_obs = al((size_t)ttot * NS * sizeof(double)), b_fwd = al((size_t)(nkeep ? ttot : 1) * NS * sizeof(double)),
+                 b_bp = al((size_t)ttot * NS * sizeof(short));
+    DBuf& arena = rt->buf("rec");
+    PS_TRY(arena.ensure(2 * b_obs + b_fwd + b_bp));
     PS_TRY(rt->buf("vit_lik").ensure((size_t)R * NS * sizeof(double)));
     if (nkeep > 0) {   // every allocation of the call before the first deviate is drawn: a caller may cut the batch again on PS_ERR_NOMEM
         PS_TRY(rt->buf("vit_att").ensure(nkeep * sizeof(double)));
@@ -443,10 +447,11 @@ int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, in
     VitReg* d_regs = rt->buf("vit_regs").as<VitReg>();
     int* d_posreg = rt->buf("vit_posreg").as<int>();
     double* d_in = rt->buf("vit_in").as<double>();
-    double* d_obs = rt->buf("vit_obs").as<double>();
-    double* d_eobs = rt->buf("vit_eobs").as<double>();
-    short* d_bp = rt->buf("vit_bp").as<short>();
-    double* d_fwd = rt->buf("vit_fwd").as<double>();
+    char* abase = (char*)arena.p;
+    double* d_obs = (double*)abase;
+    double* d_eobs = (double*)(abase + b_obs);
+    double* d_fwd = (double*)(abase + 2 * b_obs);
+    short* d_bp = (short*)(abase + 2 * b_obs + b_fwd);
     double* d_lik = rt->buf("vit_lik").as<double>();
     PS_TRY(rt->up(d_regs, regs.data(), R * sizeof(VitReg)));
     PS_TRY(rt->up(d_posreg, pos_reg.data(), (size_t)ttot * sizeof(int)));
