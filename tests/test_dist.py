@@ -301,3 +301,33 @@ def test_event_sharded_scoring_equals_unsharded_world1_and_world2():
         WORKER = keep
     assert one["all_ranks_equal_unsharded"] and two["all_ranks_equal_unsharded"] and two["world"] == 2
     assert one["n"] == two["n"] == 150 and one["npos"] == two["npos"] > 0
+
+
+def test_stream_batches_keeps_item_order_and_reraises():
+    """poreseq_amd.dist.stream_batches: items stream through `in_flight` host threads (a thread takes the next item when its own is
+    done), results come back in item order, the first exception is re-raised; no GPU involved (the workers' entry hint is moot here)."""
+    import threading
+    import time
+    from poreseq_amd import dist as psdist
+    seen = []
+    lock = threading.Lock()
+
+    def work(k):
+        time.sleep(0.02 * ((7 - k) % 3))
+        with lock:
+            seen.append(threading.get_ident())
+        return k * k
+
+    assert psdist.stream_batches(range(7), work, in_flight=3) == [k * k for k in range(7)]
+    assert 1 < len(set(seen)) <= 3
+    assert psdist.stream_batches(range(3), work, in_flight=1) == [0, 1, 4]
+    assert psdist.stream_batches([5], work, in_flight=4) == [25]
+    assert psdist.stream_batches(range(2), work, in_flight=8) == [0, 1]          # more slots than items
+
+    def bad(k):
+        if k == 2:
+            raise ValueError("item 2")
+        return k
+
+    with pytest.raises(ValueError, match="item 2"):
+        psdist.stream_batches(range(5), bad, in_flight=2)
