@@ -195,6 +195,11 @@ int ps_set_sweep_min(int32_t min_alignments);
  * from `min_sweeps` sweeps on, one wavefront per sweep.  Negative: the default (PORESEQ_SWEEP2_MIN, else never:
  * their records cap a launch at a few hundred sweeps, where a workgroup per sweep is twice as fast — DESIGN.md section 4). */
 int ps_set_sweep2_min(int32_t min_sweeps);
+/* Alignment::update batches whose edit lists read at most a quarter of the matrix columns (every ScoreMutations call of a consensus
+ * schedule except Refine's point edits at every position): from `min_sweeps` sweeps on, one wavefront per sweep that stores the
+ * {main, stay} records of the columns scoreMutation / columnMax will read (cpp/Alignment.cpp:447-512, cpp/Alignment.h:181-214) and
+ * nothing else of the score matrices.  Negative: the default (PORESEQ_SPARSE_MIN, else 160).  Results do not depend on it. */
+int ps_set_sparse_min(int32_t min_sweeps);
 
 /* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
  * algorithmic bytes of the named kernel class ("fill" = k_fill, "sweep" = k_sweep / k_sweep2, "score", "viterbi", "sw") since reset. */

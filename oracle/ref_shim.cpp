@@ -225,6 +225,7 @@ int ps_srand(uint32_t seed) { srand(seed); return PS_OK; }
 int ps_rand_draw(int64_t n, double* out) { for (int64_t k = 0; k < n; k++) out[k] = rand() / (double(RAND_MAX) + 1); return PS_OK; }
 int ps_set_sweep_min(int32_t) { return PS_OK; }
 int ps_set_sweep2_min(int32_t) { return PS_OK; }
+int ps_set_sparse_min(int32_t) { return PS_OK; }
 int ps_prof_enable(int32_t) { return PS_OK; }
 int ps_prof_reset(void) { return PS_OK; }
 int ps_prof_get(const char*, double* ms, int64_t* n, double* b) { if (ms) *ms = 0; if (n) *n = 0; if (b) *b = 0; return PS_OK; }

@@ -80,6 +80,7 @@ SYMBOLS = {
     "ps_debug_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_dp, c_dp, c_u8p, c_u8p]),
     "ps_set_sweep_min": (C.c_int, [C.c_int32]),
     "ps_set_sweep2_min": (C.c_int, [C.c_int32]),
+    "ps_set_sparse_min": (C.c_int, [C.c_int32]),
     "ps_prof_enable": (C.c_int, [C.c_int32]),
     "ps_prof_reset": (C.c_int, []),
     "ps_prof_get": (C.c_int, [C.c_char_p, c_dp, c_i64p, c_dp]),
@@ -381,6 +382,10 @@ class CApi:
     def set_sweep2_min(self, n):
         """Alignment::update batches (forward + backward sweep per alignment) of at least n sweeps run one wavefront per sweep"""
         self.check(self.lib.ps_set_sweep2_min(int(n)))
+
+    def set_sparse_min(self, n):
+        """Alignment::update batches whose edit lists read few matrix columns: strip sweeps with kept columns from n sweeps on"""
+        self.check(self.lib.ps_set_sparse_min(int(n)))
 
     def prof_enable(self, on):
         self.check(self.lib.ps_prof_enable(int(on)))   # 1: synchronous per launch, 2: event pairs queued and read by prof_get

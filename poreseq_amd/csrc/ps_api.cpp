@@ -310,6 +310,7 @@ int ps_rand_draw(int64_t n, double* out) {
 
 int ps_set_sweep_min(int32_t n) { sweep_min_set(n); return PS_OK; }
 int ps_set_sweep2_min(int32_t n) { sweep2_min_set(n); return PS_OK; }
+int ps_set_sparse_min(int32_t n) { sparse_min_set(n); return PS_OK; }
 
 int ps_prof_enable(int32_t on) {
     NEED_RT();

@@ -14,6 +14,7 @@
 #include <functional>
 #include <numeric>
 #include <mutex>
+#include <condition_variable>
 #include <thread>
 #include <cstdio>
 #include <ctime>
@@ -339,6 +340,8 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
     d.fastdiv = 1;
     jobs.clear();
     maxS = 0; maxC = 0; maxn = 0; maxlbn = 0;
+    sparse = ndir == 2 && !specs.empty();
+    nkeep.clear();
     constexpr int ST_PAD = 8;   // ints of -1 around every state list: k_fill fetches four states per 16-byte load
     int64_t st_tot = 0, lb_tot = 0, lo_tot = 0, col_tot = 0;
     std::vector<int> h_states;
@@ -379,6 +382,9 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
             j.col_off[d] = col_tot; col_tot += j.C + 1;
         }
         j.ra = s.ra; j.rl = s.rl; j.ri = s.ri; j.out = s.out;
+        j.keep[0] = s.keep[0]; j.keep[1] = s.keep[1];
+        if (!s.keep[0] || !s.keep[1]) sparse = false;
+        nkeep.push_back(s.nkeep[0]); nkeep.push_back(s.nkeep[1]);
         maxS = std::max(maxS, j.S); maxC = std::max(maxC, j.C); maxn = std::max(maxn, j.n0); maxlbn = std::max(maxlbn, j.lbn);
         jobs.push_back(j);
     }
@@ -414,19 +420,85 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
 // 288 GB -> 47 GB per runtime up to four threads: a lone region's 170 candidate alignments (24 GB) stay one launch; a lock-step
 // batch of 16 regions takes ~170 workgroups of two 10 kb sweeps per launch.  Callers size their batches on a guess of the band
 // footprint (guess_slots) and split when realign() finds the matrices 20 % over the share, or the device short of memory.
-double device_share_bytes() {
-    if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
+static size_t device_total_bytes() {
     static std::atomic<size_t> dev_total(0);       // the device's memory size does not change: asked once
     size_t tot = dev_total.load();
     if (!tot) {
         size_t fr = 0;
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 48e9;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 0;
         dev_total.store(tot);
     }
-    // (every runtime also holds ~4 % of an MI355X outside the matrix pools at 10 kb x 20 regions — Viterbi tables, Smith-Waterman
-    //  checkpoints, band tables: beyond seven runtimes the matrix fraction gives way)
+    return tot;
+}
+
+double device_share_bytes() {
+    if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
+    const size_t tot = device_total_bytes();
+    if (!tot) return 32e9;
+    // (every runtime also holds a few GB outside these pools — Viterbi tables, Smith-Waterman checkpoints, band tables — and the
+    //  full score matrices of Refine-sized ScoreMutations calls live in the process-wide slabs below: 38 % of the device)
     const int nrt = std::max(4, peak_runtimes());
-    return std::max(2e9, std::min(0.65, 0.95 - 0.04 * nrt) * (double)tot / nrt);
+    return std::max(2e9, 0.42 * (double)tot / nrt);
+}
+
+// ---- slabs for full score matrices -----------------------------------------------------------------------------------------
+// Only a ScoreMutations call whose edit list reads most columns (Refine / ScorePoints: point edits at every position, ~4 % of a
+// consensus schedule's calls) keeps full forward + backward matrices: 265 MB per 10 kb event, 53 GB for a lock-step call of 20
+// regions.  Sizing every runtime's pools for that (round 3: 65 % of the device divided by the batches in flight) made the number of
+// batches in flight a memory question.  Instead the process keeps a few slabs (PORESEQ_SLABS, default 2, of PORESEQ_SLAB_GB,
+// default 19 % of the device each: 55 GB on an MI355X), allocated on first use and never freed; a dense call takes one for its
+// duration (fills, backtrace, edit scoring, read-back) and waits when all are taken.  Nothing is acquired while a slab is held.
+namespace {
+struct Slab { char* p = nullptr; size_t bytes = 0; bool busy = false; };
+std::mutex g_slab_mu;
+std::condition_variable g_slab_cv;
+std::vector<Slab*> g_slabs;
+}  // namespace
+static int slab_count() { static const int n = getenv("PORESEQ_SLABS") ? std::max(1, atoi(getenv("PORESEQ_SLABS"))) : 2; return n; }
+size_t slab_bytes() {
+    static const double gb = getenv("PORESEQ_SLAB_GB") ? atof(getenv("PORESEQ_SLAB_GB")) : 0.0;
+    if (gb > 0) return (size_t)(gb * 1e9);
+    const size_t tot = device_total_bytes();
+    return tot ? (size_t)(0.19 * (double)tot) : (size_t)48e9;
+}
+// bytes of full matrices one dense call may place: the slab, or PORESEQ_MAX_BATCH_GB when set (tests: tiny budgets)
+double dense_cap_bytes() {
+    if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return std::min(g * 1e9, (double)slab_bytes()); }
+    return (double)slab_bytes();
+}
+void SlabHold::release() {
+    if (!s) return;
+    if (drain) (void)hipStreamSynchronize(drain);   // (a no-op on the normal path: the call has read its results back)
+    { std::lock_guard<std::mutex> lk(g_slab_mu); ((Slab*)s)->busy = false; }
+    s = nullptr; p = nullptr; bytes = 0;
+    g_slab_cv.notify_one();
+}
+int slab_acquire(SlabHold* h) {
+    std::unique_lock<std::mutex> lk(g_slab_mu);
+    for (;;) {
+        for (Slab* sl : g_slabs) if (!sl->busy) { sl->busy = true; h->s = sl; h->p = sl->p; h->bytes = sl->bytes; return PS_OK; }
+        if ((int)g_slabs.size() < slab_count()) {
+            Slab* sl = new Slab();
+            size_t want = slab_bytes();
+            hipError_t e = hipMalloc((void**)&sl->p, want);
+            if (e != hipSuccess) {   // the device is fuller than expected: idle runtimes' pools first, then a smaller slab
+                (void)hipGetLastError();
+                (void)trim_idle_runtimes();
+                for (int k = 0; k < 3 && e != hipSuccess; k++) { if (k) want = want / 4 * 3; e = hipMalloc((void**)&sl->p, want); if (e != hipSuccess) (void)hipGetLastError(); }
+            }
+            if (e != hipSuccess) {
+                delete sl;
+                if (!g_slabs.empty()) { g_slab_cv.wait(lk); continue; }   // make do with the slabs there are
+                return fail(PS_ERR_NOMEM, std::string("hipMalloc of a ") + std::to_string(want >> 20) + " MB slab for full score matrices: " + hipGetErrorString(e));
+            }
+            sl->bytes = want; sl->busy = true;
+            g_pool_bytes += (long long)want;
+            g_slabs.push_back(sl);
+            h->s = sl; h->p = sl->p; h->bytes = sl->bytes;
+            return PS_OK;
+        }
+        g_slab_cv.wait(lk);
+    }
 }
 
 // The DP matrices ("rec": 16-byte records, or a strip sweep's step codes, which alias it; "flg": step words) are the only big pools,
@@ -434,7 +506,15 @@ double device_share_bytes() {
 // keep the sum below the device: a runtime whose pools were sized for a much larger share than today's gives them back before
 // re-sizing, and no matrix pool grows into the last 8 % of the device (small buffers of every runtime live there) — PS_ERR_NOMEM
 // instead, which callers that can split turn into smaller batches.
-static int ensure_matrix_pools(Runtime* rt, size_t need_rec, size_t need_flg, bool can_split) {
+static int ensure_matrix_pools(Runtime* rt, const Batch& bt, size_t need_rec, size_t need_flg, bool can_split, void** rec_out, void** flg_out) {
+    if (bt.ext) {   // full matrices of a dense ScoreMutations call: carved out of the slab the caller holds
+        const size_t r = (need_rec + 255) & ~(size_t)255;
+        if (r + need_flg > bt.ext_bytes)
+            return fail(PS_ERR_NOMEM, "the score matrices of this call (" + std::to_string((r + need_flg) >> 20) + " MB) do not fit a slab of " + std::to_string(bt.ext_bytes >> 20) +
+                                      " MB (PORESEQ_SLAB_GB)");
+        *rec_out = bt.ext; *flg_out = bt.ext + r;
+        return PS_OK;
+    }
     DBuf& rec = rt->buf("rec");
     DBuf& flg = rt->buf("flg");
     size_t fr = 0, tot = 0;
@@ -451,6 +531,7 @@ static int ensure_matrix_pools(Runtime* rt, size_t need_rec, size_t need_flg, bo
     }
     PS_TRY(rec.ensure(need_rec));
     if (need_flg) PS_TRY(flg.ensure(need_flg));
+    *rec_out = rec.p; *flg_out = flg.p;
     return PS_OK;
 }
 
@@ -465,9 +546,10 @@ int Batch::place(Runtime* rt, int P_, bool can_split) {
         for (int dd = 0; dd < ndir; dd++) { j.mat_off[dd] = mat_tot + (int64_t)MAT_FRONT * P; mat_tot += (j.S + MAT_FRONT + MAT_BACK) * P; }
     }
     cells = mat_tot;
-    PS_TRY(ensure_matrix_pools(rt, (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(double2), (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short), can_split));
+    void *prec = nullptr, *pflg = nullptr;
+    PS_TRY(ensure_matrix_pools(rt, *this, (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(double2), (size_t)std::max<int64_t>(mat_tot, 1) * sizeof(unsigned short), can_split, &prec, &pflg));
     PS_TRY(rt->up(rt->buf("jobs").p, jobs.data(), jobs.size() * sizeof(JobD)));
-    d.rec = rt->buf("rec").as<double2>(); d.flg = rt->buf("flg").as<unsigned short>();
+    d.rec = (double2*)prec; d.flg = (unsigned short*)pflg;
     return PS_OK;
 }
 
@@ -621,9 +703,13 @@ int Align::refs_to_host(Runtime* rt) {
 // cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
 static int sweep_min_default() { static const int v = getenv("PORESEQ_SWEEP_MIN") ? atoi(getenv("PORESEQ_SWEEP_MIN")) : 400; return v; }
 static int sweep2_min_default() { static const int v = getenv("PORESEQ_SWEEP2_MIN") ? atoi(getenv("PORESEQ_SWEEP2_MIN")) : (1 << 30); return v; }
-static std::atomic<int> g_sweep_min(-1), g_sweep2_min(-1);
+// column-sparse Alignment::update (ScoreMutations whose edit list reads few columns): from this many sweeps on
+static int sparse_min_default() { static const int v = getenv("PORESEQ_SPARSE_MIN") ? atoi(getenv("PORESEQ_SPARSE_MIN")) : 160; return v; }
+static std::atomic<int> g_sweep_min(-1), g_sweep2_min(-1), g_sparse_min(-1);
 void sweep_min_set(int n) { g_sweep_min.store(n); }
 void sweep2_min_set(int n) { g_sweep2_min.store(n); }
+void sparse_min_set(int n) { g_sparse_min.store(n); }
+static int sparse_min() { return g_sparse_min.load() >= 0 ? g_sparse_min.load() : sparse_min_default(); }
 bool sweep_enabled() { static const bool off = getenv("PORESEQ_NO_SWEEP") != nullptr; return !off; }
 
 // device bytes one forward-only job of AlignData a (n0 levels against C states) will probably take: step codes of a strip sweep,
@@ -652,7 +738,7 @@ static int realign_sweep(Runtime* rt, Batch& b, double cap) {
         int* w = nullptr;
         PS_TRY(rt->down(&w, b.sd.maxwin, (size_t)1));
         PS_HIP(hipStreamSynchronize(rt->stream));
-        { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign (strip sweep): %d jobs x %d, K = %d, widest window %d strips\n", b.d.njobs, b.ndir, K, *w); }
+        { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign (strip sweep%s): %d jobs x %d, K = %d, widest window %d strips\n", b.sparse ? ", kept columns" : "", b.d.njobs, b.ndir, K, *w); }
         if (*w <= sweep_win_max()) break;
         K = sweep_next_k(K);
         if (!K) { for (JobD& j : b.jobs) j.K = 0; return -1; }
@@ -660,7 +746,7 @@ static int realign_sweep(Runtime* rt, Batch& b, double cap) {
     const double bytes = (double)b.sweep_code_bytes + 16.0 * (double)b.sweep_recs;
     if (cap > 0 && bytes > cap) {
         static const bool trace = getenv("PORESEQ_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[ps] realign (strip sweep): %.2f GB of step codes%s at K = %d, over the share: split\n", bytes * 1e-9, b.ndir == 2 ? " and records" : "", K);
+        if (trace) fprintf(stderr, "[ps] realign (strip sweep): %.2f GB of step codes%s at K = %d, over the share: split\n", bytes * 1e-9, b.ndir == 2 ? (b.sparse ? " and kept columns" : " and records") : "", K);
         b.P = 0;
         return PS_SPLIT;
     }
@@ -669,12 +755,14 @@ static int realign_sweep(Runtime* rt, Batch& b, double cap) {
         // with both directions the records take that pool and the codes the step words'
         const size_t need_rec = b.ndir == 2 ? (size_t)std::max<int64_t>(b.sweep_recs, 1) * sizeof(double2) : (size_t)std::max<int64_t>(b.sweep_code_bytes, 1);
         const size_t need_flg = b.ndir == 2 ? (size_t)std::max<int64_t>(b.sweep_code_bytes, 1) : 0;
-        const int rc = ensure_matrix_pools(rt, need_rec, need_flg, cap > 0);
+        void *prec = nullptr, *pflg = nullptr;
+        Batch own;   // (kept columns and step codes are small: always the runtime's own pools)
+        const int rc = ensure_matrix_pools(rt, b.sparse || b.ndir == 1 ? own : b, need_rec, need_flg, cap > 0, &prec, &pflg);
         if (rc == PS_ERR_NOMEM && cap > 0) { b.P = 0; return PS_SPLIT; }
         PS_TRY(rc);
-        b.sd.codes = b.ndir == 2 ? rt->buf("flg").as<unsigned char>() : rt->buf("rec").as<unsigned char>();
+        b.sd.codes = b.ndir == 2 ? (unsigned char*)pflg : (unsigned char*)prec;
         if (b.ndir == 2) {
-            b.d.rec = rt->buf("rec").as<double2>(); b.d.flg = nullptr;
+            b.d.rec = (double2*)prec; b.d.flg = nullptr;
             b.d.s_sj = b.sd.sj; b.d.s_band = b.sd.band; b.d.s_qlo = b.sd.qlo; b.d.s_qhi = b.sd.qhi;
             PS_TRY(rt->up(rt->buf("jobs").p, b.jobs.data(), b.jobs.size() * sizeof(JobD)));   // JobD.K, JobD.mat_off
             PS_HIP(hipMemsetAsync(b.d.cmax, 0, b.ncols * sizeof(double), rt->stream));
@@ -691,12 +779,22 @@ int realign(Runtime* rt, Batch& b, double cap) {
     // forward-only batches take the strip sweep (one wave per alignment) from ps_set_sweep_min / PORESEQ_SWEEP_MIN alignments on
     // (default 400); a smaller batch alone on the chip finishes sooner with a workgroup per alignment (k_fill: ~11 ms against
     // ~25 ms for a 10 kb sweep; with several batches in flight the two take the same time)
+    if (b.sparse && !(sweep_enabled() && b.d.njobs * 2 >= sparse_min())) b.sparse = false;
     const int sweep_min = b.ndir == 1 ? (g_sweep_min.load() >= 0 ? g_sweep_min.load() : sweep_min_default())
-                                      : (g_sweep2_min.load() >= 0 ? g_sweep2_min.load() : sweep2_min_default());
-    if (sweep_enabled() && b.d.njobs * b.ndir >= sweep_min) {
+                                      : (b.sparse ? 0 : (g_sweep2_min.load() >= 0 ? g_sweep2_min.load() : sweep2_min_default()));
+    // (a forward-only batch below the threshold whose skewed matrices would not fit this runtime's share — a third of FindMutations'
+    //  candidate batches with many batches in flight — takes the sweep as well: 7 MB of step codes per alignment instead of 140 MB)
+    bool too_big = false;
+    if (b.ndir == 1 && sweep_enabled() && b.d.njobs < sweep_min) {
+        double est = 0;
+        for (const JobD& j : b.jobs) est += (double)(j.S + MAT_FRONT + MAT_BACK) * std::min(1024, std::max(64, (((2 * j.W + 1) * 10 / 19 + 9 + 63) / 64) * 64)) * 18.0;
+        too_big = est > device_share_bytes();
+    }
+    if (sweep_enabled() && (b.d.njobs * b.ndir >= sweep_min || too_big)) {
         const int rc = realign_sweep(rt, b, cap);
         if (rc != -1) return rc;
     }
+    b.sparse = false;   // (a band too wide for any strip height: skewed matrices)
     PS_TRY(launch_begin(rt, b.d));
     PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
     PS_TRY(launch_lo(rt, b.d, b.ndir, b.maxS));
@@ -764,7 +862,7 @@ int guess_slots(const Align* a) {
 // runtime's device share; otherwise the batch is cut into the fewest sub-batches that fit, of about equal size (a remainder of
 // two regions behind two full sub-batches would cost a whole launch's latency for a tenth of the work)
 static size_t fit_share(const std::vector<Align*>& as, size_t k0, int ndir) {
-    const double cap = device_share_bytes();
+    const double cap = ndir == 2 ? dense_cap_bytes() : device_share_bytes();   // (full forward + backward matrices live in a slab)
     auto need = [&](size_t k) {
         const Align* a = as[k];
         const int P = guess_slots(a);
@@ -890,6 +988,8 @@ namespace {
 struct EditPlan {
     int M = 0, ncolmax = 1, extra = 0, nr0 = 0;
     std::vector<int> start, mlen, cm, ncol, skip, oldidx, states, r0s, cls[4];
+    std::vector<int> keep[2];   // per direction: kept-column index of column 0 .. C + 1, or -1 (plan_keep)
+    int nkeep[2] = {0, 0};
     int rc = PS_OK;
 };
 }  // namespace
@@ -921,6 +1021,32 @@ static void plan_edits(const Align* a, const std::vector<Mut>& muts, EditPlan* p
     }
     p->ncolmax = ncolmax;
     p->extra = std::max(extra, 0) + 2;
+}
+
+// The matrix columns the scoring of this list will read (k_old / k_score, cpp/Alignment.cpp:447-512, cpp/Alignment.h:181-214):
+// per edit the forward column it is spliced behind, max(start - 4, 0), the column pair of its old score, max(start - 3, 1) forward
+// and C - that + 1 backward, and the backward column its target is combined with — with the kernels' own clamping.  Column 0 (the
+// blank column) is never read from the records.
+static void plan_keep(const Align* a, EditPlan* p) {
+    const int C = (int)a->states.size();
+    for (int d = 0; d < 2; d++) { p->keep[d].assign((size_t)C + 2, -1); p->nkeep[d] = 0; }
+    auto clampc = [&](int c) { return (unsigned)c >= (unsigned)(C + 1) ? C : c; };
+    for (int i = 0; i < p->M; i++) {
+        if (p->skip[i]) continue;
+        const int start = p->start[i];
+        const int sidx = std::max(start - 4, 0);
+        const int tcol = std::min(start + p->mlen[i] + 1, sidx + p->ncol[i]);
+        const int backind = clampc(p->cm[i] - tcol + 1);
+        const int r0 = std::max(start - 3, 1);
+        const int raf = clampc(r0), rab = clampc(C - r0 + 1);
+        const int sf = clampc(sidx);
+        if (sf > 0) p->keep[0][sf] = 0;
+        if (raf > 0) p->keep[0][raf] = 0;
+        if (backind > 0) p->keep[1][backind] = 0;
+        if (rab > 0) p->keep[1][rab] = 0;
+    }
+    for (int d = 0; d < 2; d++)
+        for (int c = 0; c <= C + 1; c++) if (p->keep[d][c] == 0) p->keep[d][c] = p->nkeep[d]++;
 }
 
 // second half of the plan (runs on host threads while the GPU realigns): edited states, distinct r0, size classes
@@ -958,18 +1084,6 @@ static void plan_tables(const Align* a, const std::vector<Mut>& muts, EditPlan* 
 // events (forward + backward of one event share a workgroup), then the edit scoring of each
 int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
                           const std::vector<std::vector<Mut>*>& outs, const std::vector<double*>* delta_out) {
-    if (fit_share(as, 0, 2) < as.size()) {   // sub-batches that fit this runtime's share of the device
-        for (size_t k0 = 0; k0 < as.size();) {
-            const size_t k1 = fit_share(as, k0, 2);
-            std::vector<double*> dsub;
-            if (delta_out) dsub.assign(delta_out->begin() + k0, delta_out->begin() + k1);
-            PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin() + k0, as.begin() + k1),
-                                         std::vector<const std::vector<Mut>*>(muts.begin() + k0, muts.begin() + k1),
-                                         std::vector<std::vector<Mut>*>(outs.begin() + k0, outs.begin() + k1), delta_out ? &dsub : nullptr));
-            k0 = k1;
-        }
-        return PS_OK;
-    }
     Tick tk("score_mutations");
     const int R = (int)as.size();
     std::vector<EditPlan> plan(R);
@@ -981,7 +1095,67 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         if (plan[k].rc != PS_OK) return fail(plan[k].rc, "negative mutation start");
         if (plan[k].ncolmax > 64 && as[k]->par.scoring_width > 511) return fail(PS_ERR_UNSUPPORTED, "edit longer than 58 bases with scoring_width > 511");
     }
+    // Which columns of the score matrices will the edit lists read?  A short list (FindMutations' found edits, the rounds of
+    // MakeMutations' recursion: tens to hundreds of edits per region) reads a few percent of them: the fills then run as strip
+    // sweeps that keep those columns only (ps_sweep.hip, k_sweeps) — a few MB per alignment instead of 2 x 110 MB.  A list that
+    // touches more than a quarter of the columns (Refine's point edits at every position) takes full matrices.
+    static const double sparse_frac = getenv("PORESEQ_SPARSE_FRAC") ? atof(getenv("PORESEQ_SPARSE_FRAC")) : 0.25;
+    bool sparse = sweep_enabled();
+    int njobs_all = 0;
+    double sparse_bytes = 0;
+    for (int k = 0; k < R && sparse; k++) {
+        const Align* a = as[k];
+        const int C = (int)a->states.size();
+        plan_keep(a, &plan[k]);
+        if (std::max(plan[k].nkeep[0], plan[k].nkeep[1]) > sparse_frac * C) sparse = false;
+        const int K = sweep_guess_k(a->par.realign_width);
+        if (!K) sparse = false;
+        njobs_all += a->E;
+        for (int e = 0; e < a->E && sparse; e++)
+            sparse_bytes += sweep_job_bytes(a->n[e], C, K) + 16.0 * (plan[k].nkeep[0] + plan[k].nkeep[1]) * (std::min(2 * a->par.realign_width + 1, a->n[e]) + 3);
+    }
+    if (sparse && 2 * njobs_all < sparse_min()) sparse = false;
+    if (tk.on) {
+        double fr = 0; size_t M = 0;
+        for (int k = 0; k < R; k++) { M += plan[k].M; if (!plan[k].keep[0].empty()) fr = std::max(fr, (double)std::max(plan[k].nkeep[0], plan[k].nkeep[1]) / std::max<size_t>(as[k]->states.size(), 1)); }
+        fprintf(stderr, "[ps] score_mutations: %d regions, %d events, %zu edits, kept columns <= %.3f of a matrix: %s\n", R, njobs_all, M, fr, sparse ? "kept columns" : "full matrices");
+    }
     tk.lap("edit sizes");
+    auto halves = [&]() {
+        const size_t h = as.size() / 2;
+        std::vector<double*> d0, d1;
+        if (delta_out) { d0.assign(delta_out->begin(), delta_out->begin() + h); d1.assign(delta_out->begin() + h, delta_out->end()); }
+        PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin(), as.begin() + h), std::vector<const std::vector<Mut>*>(muts.begin(), muts.begin() + h),
+                                     std::vector<std::vector<Mut>*>(outs.begin(), outs.begin() + h), delta_out ? &d0 : nullptr));
+        return score_mutations_multi(rt, std::vector<Align*>(as.begin() + h, as.end()), std::vector<const std::vector<Mut>*>(muts.begin() + h, muts.end()),
+                                     std::vector<std::vector<Mut>*>(outs.begin() + h, outs.end()), delta_out ? &d1 : nullptr);
+    };
+    if (sparse && R > 1 && sparse_bytes > device_share_bytes()) return halves();
+    if (!sparse && fit_share(as, 0, 2) < as.size()) {   // sub-batches that fit this runtime's share of the device
+        for (size_t k0 = 0; k0 < as.size();) {
+            const size_t k1 = fit_share(as, k0, 2);
+            std::vector<double*> dsub;
+            if (delta_out) dsub.assign(delta_out->begin() + k0, delta_out->begin() + k1);
+            PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin() + k0, as.begin() + k1),
+                                         std::vector<const std::vector<Mut>*>(muts.begin() + k0, muts.begin() + k1),
+                                         std::vector<std::vector<Mut>*>(outs.begin() + k0, outs.begin() + k1), delta_out ? &dsub : nullptr));
+            k0 = k1;
+        }
+        return PS_OK;
+    }
+    // the kept-column tables of all AlignData in one block (before the jobs are built: their descriptors point into it)
+    std::vector<const int*> d_keep(2 * (size_t)R, nullptr);
+    if (sparse) {
+        size_t tot = 0;
+        for (int k = 0; k < R; k++) tot += plan[k].keep[0].size() + plan[k].keep[1].size();
+        DBuf& kb = rt->buf("keep");
+        PS_TRY(kb.ensure(std::max<size_t>(tot, 1) * sizeof(int)));
+        std::vector<int> hk;
+        hk.reserve(tot);
+        for (int k = 0; k < R; k++)
+            for (int d = 0; d < 2; d++) { d_keep[2 * k + d] = kb.as<int>() + hk.size(); hk.insert(hk.end(), plan[k].keep[d].begin(), plan[k].keep[d].end()); }
+        PS_TRY(rt->up(kb.p, hk.data(), hk.size() * sizeof(int)));
+    }
     // Alignment::update for every event of every AlignData: enqueued now, so that the fills run while the host prepares the edit tables
     std::vector<JobSpec> specs;
     std::vector<int> job0(R, 0);
@@ -994,23 +1168,23 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
             JobSpec s;
             s.a = a; s.ev = e; s.states = &a->states;
             s.ra = a->d_ra + a->off[e]; s.rl = a->d_rl + a->off[e]; s.ri = a->d_ri + a->off[e]; s.out = a->d_out + e;
+            if (sparse) for (int d = 0; d < 2; d++) { s.keep[d] = d_keep[2 * k + d]; s.nkeep[d] = plan[k].nkeep[d]; }
             specs.push_back(s);
         }
     }
     if (specs.empty()) return PS_OK;
     Batch b;
+    SlabHold slab;   // full matrices: one of the process's slabs for the duration of this call (released at every return)
+    if (!sparse) {
+        PS_TRY(slab_acquire(&slab));
+        slab.drain = rt->stream;
+        b.ext = slab.p; b.ext_bytes = R > 1 ? std::min(slab.bytes, (size_t)dense_cap_bytes()) : slab.bytes;
+        tk.lap("slab wait");
+    }
     PS_TRY(b.build(rt, specs, 2, extra));
     {
-        const int rc = realign(rt, b, R > 1 ? 1.2 * device_share_bytes() : 0.0);
-        if (rc == PS_SPLIT) {   // bands wider than fit_share guessed: two halves, one after the other
-            const size_t h = as.size() / 2;
-            std::vector<double*> d0, d1;
-            if (delta_out) { d0.assign(delta_out->begin(), delta_out->begin() + h); d1.assign(delta_out->begin() + h, delta_out->end()); }
-            PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin(), as.begin() + h), std::vector<const std::vector<Mut>*>(muts.begin(), muts.begin() + h),
-                                         std::vector<std::vector<Mut>*>(outs.begin(), outs.begin() + h), delta_out ? &d0 : nullptr));
-            return score_mutations_multi(rt, std::vector<Align*>(as.begin() + h, as.end()), std::vector<const std::vector<Mut>*>(muts.begin() + h, muts.end()),
-                                         std::vector<std::vector<Mut>*>(outs.begin() + h, outs.end()), delta_out ? &d1 : nullptr);
-        }
+        const int rc = realign(rt, b, R > 1 ? (sparse ? 1.2 * device_share_bytes() : (double)b.ext_bytes) : 0.0);
+        if (rc == PS_SPLIT) { slab.release(); return halves(); }   // bands wider than guessed: two halves, one after the other
         PS_TRY(rc);
     }
     for (Align* a : as) a->host_refs_valid = false;
@@ -1049,7 +1223,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         // edit positions on more than a quarter of the columns: column-pair maxima of ALL columns in one coalesced pass (k_oldall)
         sa.oldall_pitch = (int64_t)as[k]->states.size() + 8;
         sa.maxS = b.maxS;
-        sa.oldall = (size_t)p.nr0 * 4 > as[k]->states.size() && p.nr0 >= 256 ? dd : nullptr;
+        sa.oldall = !b.sparse && (size_t)p.nr0 * 4 > as[k]->states.size() && p.nr0 >= 256 ? dd : nullptr;   // (k_oldall walks full matrices)
         if (sa.oldall) PS_HIP(hipMemsetAsync(sa.oldall, 0, (size_t)as[k]->E * sa.oldall_pitch * sizeof(double), rt->stream));
         dd += (size_t)as[k]->E * sa.oldall_pitch;
         if (!p.M || !as[k]->E) { sa.njobs = 0; sa.nitems_per_job = 0; }   // nothing to score for this AlignData: its blocks leave at once

@@ -33,6 +33,10 @@ struct JobSpec {
     const std::vector<int>* states = nullptr;
     double *ra = nullptr, *rl = nullptr, *ri = nullptr;  // device arrays of the job
     JobOut* out = nullptr;                               // device result record of the job
+    // column-sparse Alignment::update (ScoreMutations with a short edit list): per direction the device table of kept-column
+    // indices (C + 2 entries, -1: not kept) and the number of kept columns
+    const int* keep[2] = {nullptr, nullptr};
+    int nkeep[2] = {0, 0};
 };
 
 // a set of alignment jobs with all their device workspaces carved out of the runtime pool
@@ -46,6 +50,10 @@ struct Batch {
     SweepD sd;
     int sweep_K = 0, sweep_maxT = 0;
     int64_t sweep_code_bytes = 0, sweep_sb = 0, sweep_recs = 0;
+    bool sparse = false;          // ndir == 2: records of the kept columns only (JobSpec.keep)
+    char* ext = nullptr;          // full matrices go here (a slab) instead of the runtime's own pools
+    size_t ext_bytes = 0;
+    std::vector<int> nkeep;       // [2 * job + direction]
     int build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir, int lb_extra);
     int place(Runtime* rt, int P, bool can_split = false);
     double fill_alg_bytes() const;
@@ -96,6 +104,7 @@ int sweep_prepare(Runtime* rt, Batch& b, int K);  // band / qlo tables + the wid
 int sweep_run(Runtime* rt, Batch& b);             // sweeps, maxima, backtrace, path scores (b.sd.codes placed by the caller)
 void sweep_min_set(int n);                        // forward-only batches of at least n alignments take the strip sweep (< 0: default)
 void sweep2_min_set(int n);                       // the same for Alignment::update batches (sweeps = 2 per alignment)
+void sparse_min_set(int n);                       // Alignment::update batches whose edit list reads few columns: strip sweeps with kept columns from n sweeps on
 int launch_likes(Runtime* rt, const BatchD& b, const LikeGroup* d_groups, int ngroups, double* d_out);   // per-base likelihood vectors on the device
 int likes_max_states();                           // longest sequence (states) k_likes takes
 bool sweep_enabled();                             // PORESEQ_NO_SWEEP unset
@@ -114,7 +123,12 @@ int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::
 int peak_runtimes();   // most host threads that ever owned a runtime at the same time
 int live_runtimes();   // host threads that currently own a runtime
 int guess_slots(const Align* a);   // anti-diagonal footprint realign() will probably choose
-double device_share_bytes();   // this runtime's share of the device memory for DP matrices
+double device_share_bytes();   // this runtime's share of the device memory for its own pools (step codes, kept columns, small matrices)
+// a process-wide slab for the full score matrices of one Refine-sized ScoreMutations call (ps_host.cpp)
+struct SlabHold { void* s = nullptr; char* p = nullptr; size_t bytes = 0; hipStream_t drain = nullptr; void release(); ~SlabHold() { release(); } };   // release() drains `drain` first: nothing in flight may still use the slab
+int slab_acquire(SlabHold* h);    // blocks while all slabs are taken
+size_t slab_bytes();
+double dense_cap_bytes();         // bytes of full matrices one call may place
 int make_mutations_multi(Runtime* rt, const std::vector<Align*>& as, std::vector<std::vector<Mut>> muts, std::vector<int>* nbases);
 // delta_out (optional): per AlignData a host array [E][M] receiving every event's term of every edit's score
 int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,

@@ -129,8 +129,10 @@ struct JobD {
     int force_inert; // realign_width == 0: every Alignment is a no-op (cpp/Alignment.cpp:85-86)
     int P;           // slots per anti-diagonal (multiple of 64, >= widest footprint + 9; k_fill_wide: multiple of 128, >= footprint + 2)
     int lbn;         // entries in each lb table (C + 2 + extra)
-    int K;           // 0: skewed matrices (k_fill); > 0: strip matrices of K rows per lane (k_sweep2): REC[step][row of the strip][lane]
-    int pad1;
+    int K;           // 0: skewed matrices (k_fill); > 0: strip matrices of K rows per lane (k_sweep2): REC[step][row of the strip][lane];
+                     // < 0: column-sparse records (k_sweeps): only the columns an edit list reads, REC[kept column][row - band start]
+    int pitch;       // column-sparse records: records per kept column (>= rows of the widest band)
+    const int* keep[2];  // column-sparse records: per direction, kept-column index of column j (0 .. C + 1) or -1
     int64_t lb_off;      // lb table the fills were made with          (int32[lbn])
     int64_t lbn_off;     // lb table after the latest backtrace        (int32[lbn])
     int64_t mat_off[2];  // record offset of anti-diagonal 0 of the forward / backward matrix
@@ -200,6 +202,7 @@ struct SweepD {
     int* maxwin;            // widest window of strips in band on one step, over the batch
     int K;
     int ndir;               // 1: forward-only jobs; 2: sweep job jd = 2 * job + direction
+    int sparse;             // ndir == 2: records of the kept columns only (JobD.keep) instead of every cell's
 };
 
 // one sequence's jobs (its events, in order) for the per-base likelihood vector of ScoreAlignments (k_likes, ps_sweep.hip)

@@ -817,8 +817,8 @@ __device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, 
     for (int jf = lo + lane; jf <= hi; jf += nl) {
         const int jb = n0 - jf + 1;
         double2 fv = make_double2(0.0, 0.0), bv = make_double2(0.0, 0.0);
-        if (raf > 0) fv = b.rec[rec_index(J, 0, jf, raf)];
-        if (rab > 0) bv = b.rec[rec_index(J, 1, jb, rab)];
+        if (raf > 0) fv = b.rec[rec_index(J, 0, jf, raf, f0)];
+        if (rab > 0) bv = b.rec[rec_index(J, 1, jb, rab, b0)];
         sm = fmax(sm, fmax(fv.x + bv.x, fv.y + bv.y));
     }
     for (int off = 1; off < nl; off <<= 1) sm = fmax(sm, __shfl_xor(sm, off));
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void k_oldall_s(BatchD b, const ScoreArgs* __r
         const int2 bb = bandB[cb];
         if (ib < bb.x || ib > bb.y) continue;                           // partner outside the backward band
         const double2 fv = rf[((int64_t)t * K + r) * 64 + lane];
-        const double2 bv = b.rec[rec_index(J, 1, ib, cb)];
+        const double2 bv = b.rec[rec_index(J, 1, ib, cb, bb.x)];
         const double v = fmax(fv.x + bv.x, fv.y + bv.y);
         if (v > 0.0) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
@@ -1091,8 +1091,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         // matrix reads walk the skewed storage with cursors instead of index arithmetic per step.  Values are those of the general
         // loop below: candidates that are switched off there (no left / diagonal neighbour, top row) are -infinity, `lik_insert`
         // or `0 + x` here, which lose to the floors exactly where the reference's never-assigned candidates do.
-        if (G < 64 && J.K == 0 && __ballot(mine && state < 0) == 0ull) {
-            const int P = J.P;
+        if (G < 64 && J.K <= 0 && __ballot(mine && state < 0) == 0ull) {
+            // (column-sparse records, J.K < 0: a column is one contiguous run of records, the cursors move by one; the wrap tests
+            //  of the skewed storage never fire)
+            const bool sp = J.K < 0;
+            const int P = sp ? 0x40000000 : J.P;
+            const unsigned stride = sp ? 1u : (unsigned)P + 1u;
             const double2* __restrict__ rf = b.rec + J.mat_off[0];
             const double2* __restrict__ rb = b.rec + J.mat_off[1];
             const double NINF = -__builtin_inf();
@@ -1102,6 +1106,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             int fslot = i >= 0 ? i % P : 0, bslot = (n0 - i + 1) % P;
             unsigned fidx = (unsigned)(max(i, 0) + sidx) * (unsigned)P + (unsigned)fslot;            // record of (i, sidx), forward matrix
             unsigned bidx = (unsigned)(n0 - i + 1 + backind) * (unsigned)P + (unsigned)bslot;        // record of (n0 - i + 1, backind), backward matrix
+            if (sp) {
+                fslot = 0; bslot = 0x7fffffff;
+                fidx = use_f ? (unsigned)J.keep[0][sidx] * (unsigned)J.pitch + (unsigned)(i - pc0) : 0u;
+                bidx = use_b ? (unsigned)J.keep[1][backind] * (unsigned)J.pitch + (unsigned)(n0 - i + 1 - bb0) : 0u;
+            }
             const double log2pi = b.log2pi, off = J.lik_offset;
             for (int t = -1; t <= span; t++) {
                 double L = wave_shr1(cm);
@@ -1135,9 +1144,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 // next row: one anti-diagonal on, one slot on (forward); one back each (backward)
                 i++;
                 const bool fw = fslot + 1 == P;
-                fidx += fw ? 1u : (unsigned)P + 1u; fslot = fw ? 0 : fslot + 1;
+                fidx += fw ? 1u : stride; fslot = fw ? 0 : fslot + 1;
                 const bool bw = bslot == 0;
-                bidx -= bw ? 1u : (unsigned)P + 1u; bslot = bw ? P - 1 : bslot - 1;
+                bidx -= bw ? 1u : stride; bslot = bw ? P - 1 : bslot - 1;
             }
         } else {
             for (int t = -1; t <= span; t++) {
@@ -1148,7 +1157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     L = 0.0;
                     if (mine && i >= p0 && i <= p1 && i >= 1) {
                         if (ch > 0) L = carry[i - p0];
-                        else if (sidx > 0) L = b.rec[rec_index(J, 0, i, sidx)].x;
+                        else if (sidx > 0) L = b.rec[rec_index(J, 0, i, sidx, pc0)].x;
                     }
                 }
                 const double D = lprev;
@@ -1180,7 +1189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                         const int jb = n0 - i + 1;
                         if (jb >= bb0 && jb <= bb1) {
                             double2 bv = make_double2(0.0, 0.0);
-                            if (backind > 0) bv = b.rec[rec_index(J, 1, jb, backind)];
+                            if (backind > 0) bv = b.rec[rec_index(J, 1, jb, backind, bb0)];
                             tm = fmax(tm, fmax(nm + bv.x, ns + bv.y));
                         }
                     }

@@ -106,13 +106,16 @@ __device__ __forceinline__ double wave_ror1(double v) {
 }
 
 // One sweep.  DIR 0 / 1: forward / backward fill (cpp/Alignment.cpp:111-274 / 280-444: the backward cell adds its emission when it
-// is LEFT, so what a lane hands down and keeps for the diagonal is {main, stay + emission, main + emission}).  FULL: the sweep of
-// an Alignment::update (ScoreMutations) — every cell's {main, stay} record goes to REC[step][row of the strip][lane] (one
-// coalesced 1 KB store per row and step) and the per-column maxima (MaxInfo, cpp/Alignment.cpp:158, 270) through a 256-column
-// LDS ring to cmax; without it (ScoreAlignments) only the forward step codes and the per-strip maxima leave the chip.
+// is LEFT, so what a lane hands down and keeps for the diagonal is {main, stay + emission, main + emission}).  MODE 0
+// (ScoreAlignments): only the forward step codes and the per-strip maxima leave the chip.  MODE 1 / 2: the sweep of an
+// Alignment::update (ScoreMutations) — also the per-column maxima (MaxInfo, cpp/Alignment.cpp:158, 270) through a 256-column LDS
+// ring to cmax, and {main, stay} records: of every cell, REC[step][row of the strip][lane] (MODE 1: one coalesced 1 KB store per
+// row and step), or only of the columns the edit list will read (MODE 2: scoreMutation / columnMax, cpp/Alignment.cpp:447-512,
+// cpp/Alignment.h:181-214, read the forward columns max(start-4, 0) and max(start-3, 1) and two backward columns per edit): the
+// lane whose column is kept (JobD.keep, fetched with the band record) writes its in-band cells to REC[kept column][row - i0].
 constexpr int RING = 256;       // columns of the maxima ring: the window's 62 + the 64 steps between two flushes, rounded up
 
-template <int K, int DIR, bool FULL, bool FD>
+template <int K, int DIR, int MODE, bool FD>
 __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, const JobD& J, const SweepJob& SJ, unsigned long long* ring) {
     const int lane = threadIdx.x;
     const int C = uni(J.C), T = uni(SJ.T), n0 = uni(J.n0);
@@ -131,7 +134,9 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     const double NINF = -__builtin_inf();
 
     // ---- what a lane fetches ahead of the step it is needed on
-    struct Ahead { v4i bd; int sp, sc; };   // bd = {p0, p1, i0, i1} of columns j - 1, j; sp / sc = 5-mer of column j - 1 / j
+    struct Ahead { v4i bd; int sp, sc, kc; };   // bd = {p0, p1, i0, i1} of columns j - 1, j; sp / sc = 5-mer of column j - 1 / j; kc: kept-column index (MODE 2)
+    gcip keep = (gcip)uni_ptr(J.keep[DIR]);
+    const int pitch = uni(J.pitch);
     auto fetch = [&](int tt, int ql) -> Ahead {
         const int q = ql + ((lane - ql) & 63);
         const int j = clampi(tt - q, 1, max(C, 1));   // (a sequence without a 5-mer has no live step; its prefetches still need an address)
@@ -145,6 +150,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (C - j));
             a.sc = s2.x; a.sp = s2.y;
         }
+        a.kc = MODE == 2 ? keep[j] : -1;
         return a;
     };
     auto model_row = [&](int state, double (&m)[8]) {
@@ -164,8 +170,8 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     double dm = NINF, de = NINF;                       // upper neighbour's main (backward: and main + emission) of the previous column
     double lbest = 0.0;                  // strictly greater wins: the first cell of the strip (column, then row) holding its maximum
     int lbt = 0, lbr = 0;
-    int flushed = 1, next_flush = 64;    // (FULL) columns below `flushed` have their maximum in memory
-    if (FULL) {
+    int flushed = 1, next_flush = 64;    // (MODE > 0) columns below `flushed` have their maximum in memory
+    if (MODE) {
         for (int k = lane; k < RING; k += 64) ring[k] = 0ull;
     }
 
@@ -214,8 +220,15 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             dm = um; de = ue;
             const double lbefore = lbest;
             unsigned cw[(K + 3) / 4];                                // (forward) the step's codes, four to a register
-            double crun = 0.0;                                       // (FULL) the lane's share of its column's maximum
+            double crun = 0.0;                                       // (MODE > 0) the lane's share of its column's maximum
             PS_GLOBAL char* recp = rec + ((size_t)t * K * 64 + lane) * 16;
+            const bool kept = MODE == 2 && a0.kc >= 0 && j >= 1 && j <= C;
+            if (MODE == 2) {
+                // records of the lane's column: row i of the band [i0, i1] at REC[kc][i - i0]; recp = the strip's first row
+                recp = rec + ((int64_t)a0.kc * pitch + (base - a0.bd.z)) * 16;
+                if (kept && !valid)   // a kept column without a 5-mer: its band reads as zeros (cpp/Alignment.cpp:162-163)
+                    for (int r = max(0, a0.bd.z - base); r <= min(K - 1, a0.bd.w - base); r++) *(PS_GLOBAL v2d*)(recp + (size_t)r * 16) = (v2d){0.0, 0.0};
+            }
 #pragma unroll
             for (int r = 0; r < K; r++) {
                 const double o = ov[r];
@@ -263,11 +276,15 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                 um = nmx;
                 us = DIR == 0 ? nsx : nsx + o;
                 if (DIR) ue = nmx + o;
-                if (FULL) {
+                if (MODE == 1) {
                     double rx;   // the stored record: the cell; zeros where there is none (the stay value of a top row is -1e300 and stays so)
                     asm("v_max_f64 %0, %1, 0" : "=v"(rx) : "v"(nmx));
                     *(PS_GLOBAL v2d*)(recp + (size_t)r * 1024) = (v2d){rx, act ? ns : 0.0};
                     crun = fmax(crun, rx);
+                }
+                if (MODE == 2) {
+                    if (act && kept) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){nm, ns};   // (a cell in band: nm >= 0)
+                    crun = fmax(crun, nmx);
                 }
                 if (DIR == 0) {
                     const bool gt = nmx > lbest;
@@ -278,7 +295,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             }
             bot_m = um; bot_s = us; bot_e = ue;
             if (DIR == 0) lbt = lbest > lbefore ? t : lbt;
-            if (FULL) atomicMax(&ring[(unsigned)j & (RING - 1)], (unsigned long long)__double_as_longlong(crun));   // (scores >= 0 order like their bit patterns; 0 is a no-op)
+            if (MODE) atomicMax(&ring[(unsigned)j & (RING - 1)], (unsigned long long)__double_as_longlong(crun));   // (scores >= 0 order like their bit patterns; 0 is a no-op)
             if (DIR == 0) {
                 // ---- the step's codes: per row group one coalesced store
                 PS_GLOBAL unsigned char* dst = codes + (size_t)t * (64 * K);
@@ -307,7 +324,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                     if (r0 >= K) break;
                 }
             }
-            if (FULL && t >= next_flush) {
+            if (MODE && t >= next_flush) {
                 // the maxima of completed columns: everything left of the column the highest strip in band is working on
                 const int jdone = min(t - QHI[t], C + 1);
                 for (int col = flushed + lane; col < jdone; col += 64) {
@@ -326,7 +343,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         ql0 = ql1; ql1 = ql2;
     }
     if (DIR == 0 && qcur >= 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
-    if (FULL)
+    if (MODE)
         for (int col = flushed + lane; col <= C; col += 64) gcmax[col] = __longlong_as_double((long long)ring[(unsigned)col & (RING - 1)]);
 }
 
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 2 
 void k_sweep(BatchD b, SweepD sw) {
     const JobD& J = b.jobs[blockIdx.x];
     if (J.out->inert) return;
-    sweep_body<K, 0, false, FD>(b, sw, J, sw.sj[blockIdx.x], nullptr);
+    sweep_body<K, 0, 0, FD>(b, sw, J, sw.sj[blockIdx.x], nullptr);
 }
 
 // Alignment::update batches: one wave per (job, direction), sweep job jd = 2 * job + direction
@@ -347,8 +364,20 @@ void k_sweep2(BatchD b, SweepD sw) {
     const int jd = blockIdx.x;
     const JobD& J = b.jobs[jd >> 1];
     if (J.out->inert) return;
-    if ((jd & 1) == 0) sweep_body<K, 0, true, FD>(b, sw, J, sw.sj[jd], ring);
-    else sweep_body<K, 1, true, FD>(b, sw, J, sw.sj[jd], ring);
+    if ((jd & 1) == 0) sweep_body<K, 0, 1, FD>(b, sw, J, sw.sj[jd], ring);
+    else sweep_body<K, 1, 1, FD>(b, sw, J, sw.sj[jd], ring);
+}
+
+// Alignment::update batches whose edit list reads few columns: the same sweeps with column-sparse records
+template <int K, bool FD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 2 : 1, K <= 10 ? 2 : 1)))
+void k_sweeps(BatchD b, SweepD sw) {
+    __shared__ unsigned long long ring[RING];
+    const int jd = blockIdx.x;
+    const JobD& J = b.jobs[jd >> 1];
+    if (J.out->inert) return;
+    if ((jd & 1) == 0) sweep_body<K, 0, 2, FD>(b, sw, J, sw.sj[jd], ring);
+    else sweep_body<K, 1, 2, FD>(b, sw, J, sw.sj[jd], ring);
 }
 
 // the global maximum and its first cell — smallest column, then smallest row (cpp/Alignment.cpp:158, 270: strict '>' over columns
@@ -537,6 +566,11 @@ static int next_k(int K) { for (int k : K_LIST) if (k > K) return k; return 0; }
 
 template <int K>
 static void sweep_launch_k(Runtime* rt, const BatchD& b, const SweepD& sw) {
+    if (sw.ndir == 2 && sw.sparse) {
+        if (b.fastdiv) hipLaunchKernelGGL((k_sweeps<K, true>), dim3(b.njobs * 2), dim3(64), 0, rt->stream, b, sw);
+        else hipLaunchKernelGGL((k_sweeps<K, false>), dim3(b.njobs * 2), dim3(64), 0, rt->stream, b, sw);
+        return;
+    }
     if (sw.ndir == 2) {
         if (b.fastdiv) hipLaunchKernelGGL((k_sweep2<K, true>), dim3(b.njobs * 2), dim3(64), 0, rt->stream, b, sw);
         else hipLaunchKernelGGL((k_sweep2<K, false>), dim3(b.njobs * 2), dim3(64), 0, rt->stream, b, sw);
@@ -567,7 +601,8 @@ int sweep_prepare(Runtime* rt, Batch& bt, int K) {
     int maxT = 0;
     for (size_t k = 0; k < bt.jobs.size(); k++) {
         JobD& j = bt.jobs[k];
-        j.K = nd == 2 ? K : 0;
+        j.K = nd == 2 ? (bt.sparse ? -1 : K) : 0;
+        if (bt.sparse) j.pitch = (std::min(2 * j.W + 1, j.n0) + 3) & ~1;   // rows of the widest band (+ slack), even: 32-byte aligned columns
         for (int d = 0; d < nd; d++) {
             SweepJob s;
             s.Q = (j.n0 + K - 1) / K;
@@ -576,7 +611,8 @@ int sweep_prepare(Runtime* rt, Batch& bt, int K) {
             s.q_off = q_tot; q_tot += s.T + Q_PAD;
             s.sb_off = sb_tot; if (d == 0) sb_tot += std::max(s.Q, 1);
             s.codes_off = code_tot; if (d == 0) code_tot += (int64_t)s.T * 64 * K;
-            if (nd == 2) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)s.T * 64 * K; }
+            if (nd == 2 && bt.sparse) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)bt.nkeep[2 * k + d] * j.pitch; }
+            else if (nd == 2) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)s.T * 64 * K; }
             maxT = std::max(maxT, s.T);
             sj[k * nd + d] = s;
         }
@@ -599,6 +635,7 @@ int sweep_prepare(Runtime* rt, Batch& bt, int K) {
     sw.codes = nullptr;
     sw.K = K;
     sw.ndir = nd;
+    sw.sparse = nd == 2 && bt.sparse ? 1 : 0;
     PS_HIP(hipMemsetAsync(sw.maxwin, 0, sizeof(int), rt->stream));
     hipLaunchKernelGGL(k_band, dim3((bt.maxC + 2 + 255) / 256, b.njobs * nd), dim3(256), 0, rt->stream, b, sw);
     hipLaunchKernelGGL(k_qlo, dim3((maxT + Q_PAD + 255) / 256, b.njobs * nd), dim3(256), 0, rt->stream, b, sw);

@@ -51,9 +51,11 @@ def fwd_kernel(request):
     api = _capi.load_hip()
     api.set_sweep_min(0 if request.param == "sweep" else 1 << 30)
     api.set_sweep2_min(0 if request.param == "sweep" else 1 << 30)
+    api.set_sparse_min(0 if request.param == "sweep" else 1 << 30)
     yield request.param
     api.set_sweep_min(-1)
     api.set_sweep2_min(-1)
+    api.set_sparse_min(-1)
 
 
 @pytest.fixture
@@ -62,6 +64,8 @@ def sweep_always():
     api = _capi.load_hip()
     api.set_sweep_min(0)
     api.set_sweep2_min(0)
+    api.set_sparse_min(0)
     yield
     api.set_sweep_min(-1)
     api.set_sweep2_min(-1)
+    api.set_sparse_min(-1)

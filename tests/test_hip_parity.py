@@ -244,6 +244,53 @@ def test_edge_cases_match_oracle():
         B.make_pa(PSAlign, draft, copy.deepcopy(events), P0).ScoreMutations([m])
 
 
+def _edit(st, o, m):
+    mi = MutationInfo(); mi.start, mi.orig, mi.mut = st, o, m
+    return mi
+
+
+@pytest.mark.parametrize("L,E,par", [(3000, 6, P0), (900, 5, dict(P0, realign_width=45.0, scoring_width=12.0)), (10000, 4, P0)])
+def test_column_sparse_score_mutations_equals_full_matrices_and_oracle(L, E, par):
+    """ScoreMutations with a short edit list keeps only the matrix columns the edits read (k_sweeps): same scores as the
+    full-matrix path (k_fill) and the oracle — edits at both ends of the sequence, past the end (skipped: -1e-6), multi-base
+    insertions / deletions, one longer than a 64-column chunk, columns next to an invalid 5-mer, an inert event, an event that
+    barely aligns, and ref_align / ref_like after the call."""
+    draft, events, truth = synth.make_region(L, E, 4100 + L, B.oracle_swalign, par)
+    ev = copy.deepcopy(events)
+    ev[1].ref_align[:] = 0                       # inert event
+    ev[2].ref_align[40:] = 0                     # barely aligned event
+    seq = draft[:L // 2] + "N" + draft[L // 2 + 1:]
+    n = len(seq)
+    rng = np.random.default_rng(L)
+    muts = synth.random_point_mutations(rng, seq, 24)
+    muts += [_edit(0, "", "TT"), _edit(0, seq[0:1], ""), _edit(1, seq[1:2], "G"), _edit(3, seq[3:5], "A"), _edit(4, "", "C"), _edit(5, seq[5:9], "G" * 30),
+             _edit(n - 1, seq[n - 1:], "A"), _edit(n - 3, seq[n - 3:n - 2], "G"), _edit(n - 6, seq[n - 6:n - 2], ""), _edit(n, "", "A"), _edit(n + 3, "", "A"),
+             _edit(n - 9, "", "ACGTACG"), _edit(L // 2 - 2, seq[L // 2 - 2:L // 2 - 1], "T"), _edit(L // 2 + 1, "", "GG"), _edit(L // 2 - 7, seq[L // 2 - 7:L // 2 + 3], "ACG"),
+             _edit(L // 3, seq[L // 3:L // 3 + 1], "T" * 70), _edit(L // 4, seq[L // 4:L // 4 + 40], ""), _edit(2 * L // 3, "", "ACGTACGTACGTACGTACGTAC")]
+    api = _capi.load_hip()
+    mk = lambda cls: B.make_pa(cls, seq, copy.deepcopy(ev), par)
+    res = []
+    for mode in ("sparse", "full", "oracle"):
+        api.set_sparse_min(0 if mode == "sparse" else 1 << 30)
+        try:
+            pa = mk(B.OraclePSAlign if mode == "oracle" else PSAlign)
+            if mode != "oracle":
+                api.prof_enable(1); api.prof_reset()
+            got = pa.ScoreMutations(muts)
+            if mode != "oracle":
+                sweeps, fills = api.prof_get("sweep")[1], api.prof_get("fill")[1]
+                api.prof_enable(0)
+                assert (sweeps, fills) == ((1, 0) if mode == "sparse" else (0, 1)), (mode, sweeps, fills)   # the path under test did run
+            res.append((scores(got), [e.ref_align.copy() for e in pa.events], [e.ref_like.copy() for e in pa.events]))
+        finally:
+            api.set_sparse_min(-1)
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0])
+        for x, y in zip(res[0][1] + res[0][2], other[1] + other[2]):
+            assert np.array_equal(x, y)
+    assert res[0][0][24 + 10] == -1e-6           # the edit past the end is skipped (cpp/MakeMutations.cpp:46-47)
+
+
 def test_mutate_with_unalignable_and_duplicate_seeds_matches_oracle():
     """explicit seed lists: a seed that does not align at all (its events get no ref_index: inert sweeps next to live ones in one
     workgroup pair), the same seed twice (likelihood cache), an odd number of seeds (an unpaired sweep)"""
