@@ -320,6 +320,7 @@ def main():
                        "note": "estimate: the clock minus the slots' average marshalling + H2D time (loads overlap other slots' work; not the metric's definition)"}
 
     out["batch_done_s"] = batch_done_s
+    out["library"] = api.info()   # stream / hardware-queue mode, runtimes, memory plan (ps_info)
     if torch.cuda.is_available():   # the slots' pools only grow: what is free now is the headroom the steps ran with
         fr, tt = torch.cuda.mem_get_info()
         out["device_memory"] = {"total_gb": tt / 1e9, "free_gb_after_timed_steps": fr / 1e9}

@@ -45,6 +45,12 @@ const char* ps_last_error(void);
 /* Name of the backend that serves this ABI ("hip-gfx950"); the test-only
  * oracle and reference shims answer "oracle-cpu" / "reference-cpp". */
 const char* ps_backend_name(void);
+/* One line about the process-wide state of the library, for logs and bench lines: how its streams get hardware queues (every
+ * stream on one priority level with a queue each — GPU_MAX_HW_QUEUES >= 8 was in force when HIP started — or dealt over the
+ * device's priority levels), runtimes (host threads inside the library), the per-runtime memory share and the slabs that hold
+ * full score matrices.  A host that binds the C ABI directly and wants the first mode starts its process with GPU_MAX_HW_QUEUES=12
+ * (or more) in the environment.  Launches nothing (it may start the HIP runtime to ask the device for its memory size). */
+int ps_info(char* out, int64_t cap);
 
 /* AlignParams — cpp/AlignUtil.h:57-66 (defaults 4.5 / 150 / 300 / 0). */
 typedef struct ps_params {

@@ -33,6 +33,7 @@ class PoreseqError(Exception):
 SYMBOLS = {
     "ps_last_error": (C.c_char_p, []),
     "ps_backend_name": (C.c_char_p, []),
+    "ps_info": (C.c_int, [C.c_char_p, C.c_int64]),
     "ps_align_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int64, C.c_int32, c_i64p,
                                   c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_char_p, c_i64p,
                                   C.POINTER(PsParams)]),
@@ -119,6 +120,12 @@ class CApi:
 
     def backend_name(self):
         return self.lib.ps_backend_name().decode()
+
+    def info(self):
+        """process-wide state of the library in one line: stream / hardware-queue mode, runtimes, memory plan"""
+        buf = C.create_string_buffer(1024)
+        self.check(self.lib.ps_info(buf, 1024))
+        return buf.value.decode()
 
     # ------------------------------------------------------------------ AlignData
     def align_create(self, sequence, events, params):

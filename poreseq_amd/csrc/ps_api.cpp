@@ -1,4 +1,5 @@
 // ps_api.cpp — the C ABI of include/poreseq_hip.h over the HIP implementation.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -20,6 +21,14 @@ extern "C" {
 
 const char* ps_last_error(void) { return last_error(); }
 const char* ps_backend_name(void) { return "hip-gfx950"; }
+int ps_info(char* out, int64_t cap) {
+    if (!out || cap <= 0) return fail(PS_ERR_BAD_ARG, "ps_info");
+    const std::string s = info_string();
+    const size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+    memcpy(out, s.data(), n);
+    out[n] = 0;
+    return PS_OK;
+}
 
 int ps_align_create(ps_align** out, const char* seq, int64_t seq_len, int32_t n_events,
                     const int64_t* level_off, const double* mean, const double* stdv,

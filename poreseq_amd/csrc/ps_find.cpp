@@ -515,11 +515,11 @@ int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::
     }
     std::vector<std::vector<std::vector<int>>> paths;
     {
-        // sub-batches of regions that fit a quarter of this runtime's device share (obs, trimmed means, back-pointers and forward
+        // sub-batches of regions that fit this runtime's device share (obs, trimmed means, back-pointers and forward
         // probabilities: 26 KB per position; ~270 MB per 10 kb region); the regions' generators keep the results the same however
         // the batch is cut; a sub-batch the device has no memory for is cut in two
         auto need = [&](size_t k) { return 26.0 * 1024.0 * (double)regs[k].T + 32.0 * (double)regs[k].T * regs[k].E; };
-        double cap = std::max(1e9, device_share_bytes() / 4);
+        double cap = std::max(1e9, 0.9 * device_share_bytes());   // (the tables live in the runtime's matrix pool, which no alignment uses during this call)
         for (size_t k0 = 0; k0 < regs.size();) {
             size_t k1 = k0;
             double acc = 0;

@@ -36,6 +36,7 @@ void Tick::lap(const char* label) {
 
 // ------------------------------------------------------------------------------------------ runtime
 static size_t trim_idle_runtimes();   // below: hands back the device pools of runtimes no thread owns
+static size_t device_total_bytes();
 static std::atomic<long long> g_pool_bytes(0);   // device memory held by the pools of all runtimes
 
 int DBuf::ensure(size_t bytes) {
@@ -44,6 +45,16 @@ int DBuf::ensure(size_t bytes) {
     if (trace) fprintf(stderr, "[ps] pool grow %zu -> %zu bytes\n", cap, bytes);
     if (p) { PS_HIP(hipFree(p)); p = nullptr; g_pool_bytes -= (long long)cap; cap = 0; }
     size_t want = std::max<size_t>(bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30), 1 << 16);   // growth slack, at most 1 GB
+    // never into the last 6 % of the device: a launch that finds no memory for the HSA runtime's own needs aborts the process
+    // (HSA_STATUS_ERROR_OUT_OF_RESOURCES) — refuse here instead, callers that can cut their batch do so on PS_ERR_NOMEM
+    if (const size_t tot = device_total_bytes()) {
+        auto over = [&](size_t w) { return (double)g_pool_bytes.load() + (double)w > 0.94 * (double)tot; };
+        if (over(want)) want = std::max<size_t>(bytes, 1 << 16);
+        if (over(want)) (void)trim_idle_runtimes();
+        if (over(want))
+            return fail(PS_ERR_NOMEM, "device pools of this process would reach " + std::to_string((size_t)((g_pool_bytes.load() + (long long)want) >> 20)) + " MB of " +
+                                      std::to_string(tot >> 20) + " MB (a buffer of " + std::to_string(want >> 20) + " MB was asked for)");
+    }
     if (hipMalloc(&p, want) != hipSuccess) {
         p = nullptr;
         (void)hipGetLastError();   // (sticky: the next launch check would report it)
@@ -163,7 +174,70 @@ static size_t trim_idle_runtimes() {
         }
     return got;
 }
-RtHolder::~RtHolder() { if (s) { std::lock_guard<std::mutex> lk(g_rt_mu); g_rt_free.push_back(s); g_rt_live--; } }
+RtHolder::~RtHolder() {
+    if (!s) return;
+    if (getenv("PORESEQ_TRACE")) {   // what this thread's runtime holds, largest first
+        std::vector<std::pair<size_t, std::string>> v;
+        size_t tot = 0;
+        for (auto& kv : s->R.pool) { v.push_back({kv.second.cap, kv.first}); tot += kv.second.cap; }
+        std::sort(v.rbegin(), v.rend());
+        std::string line = "[ps] runtime handed back: " + std::to_string(tot >> 20) + " MB of device pools:";
+        for (size_t k = 0; k < v.size() && k < 12; k++) line += " " + v[k].second + " " + std::to_string(v[k].first >> 20);
+        fprintf(stderr, "%s\n", line.c_str());
+    }
+    std::lock_guard<std::mutex> lk(g_rt_mu);
+    g_rt_free.push_back(s);
+    g_rt_live--;
+}
+
+// How the runtimes' streams get hardware queues (see make_stream below).  GPU_MAX_HW_QUEUES only counts when HIP read it, i.e. when
+// it was in the environment before the HIP runtime started: either the process was started with it (/proc/self/environ is the
+// environment at exec, later setenv calls do not show there), or the poreseq_amd package exported it at import after checking that
+// nothing in the process had opened the GPU yet (it then sets PORESEQ_HWQ_SET_BY_PACKAGE=1).  A value that appeared any other way
+// is not trusted: seven streams on four queues of ONE priority level would be the slowest arrangement of all (108 against 141 kb/s).
+static int hwq_from_exec_env() {
+    static const int v = [] {
+        FILE* f = fopen("/proc/self/environ", "rb");
+        if (!f) return 0;
+        std::string all;
+        char buf[4096];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) all.append(buf, n);
+        fclose(f);
+        const std::string key = "GPU_MAX_HW_QUEUES=";
+        for (size_t at = 0; at < all.size();) {
+            const size_t end = all.find('\0', at);
+            const std::string kv = all.substr(at, end == std::string::npos ? std::string::npos : end - at);
+            if (kv.compare(0, key.size(), key) == 0) return atoi(kv.c_str() + key.size());
+            if (end == std::string::npos) break;
+            at = end + 1;
+        }
+        return 0;
+    }();
+    return v;
+}
+int hwq_mode(std::string* why) {
+    static int mode = -1;
+    static std::string reason;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (mode < 0) {
+        const char* e = getenv("GPU_MAX_HW_QUEUES");
+        const int now = e ? atoi(e) : 0;
+        const char* pk = getenv("PORESEQ_HWQ_SET_BY_PACKAGE");
+        if (getenv("PORESEQ_ONE_PRIORITY")) { mode = 1; reason = "one priority level (PORESEQ_ONE_PRIORITY)"; }
+        else if (getenv("PORESEQ_PRIORITY_LEVELS")) { mode = 0; reason = "streams dealt over the priority levels (PORESEQ_PRIORITY_LEVELS)"; }
+        else if (hwq_from_exec_env() >= 8) { mode = 1; reason = "one priority level, a hardware queue per stream (GPU_MAX_HW_QUEUES=" + std::to_string(hwq_from_exec_env()) + " in the process's start-up environment)"; }
+        else if (now >= 8 && pk && atoi(pk) == 1) { mode = 1; reason = "one priority level, a hardware queue per stream (GPU_MAX_HW_QUEUES=" + std::to_string(now) + " exported by the poreseq_amd package before HIP started)"; }
+        else {
+            mode = 0;
+            reason = now >= 8 ? "streams dealt over the priority levels (GPU_MAX_HW_QUEUES=" + std::to_string(now) + " appeared after start-up without the package's guarantee that HIP had not started: not trusted)"
+                              : "streams dealt over the priority levels (HIP's default of 4 hardware queues per level)";
+        }
+    }
+    if (why) *why = reason;
+    return mode;
+}
 
 int second_stream(Runtime* rt, hipStream_t* out) {
     // One stream per runtime as soon as several host threads drive the GPU (lock-step batches in flight): HIP maps streams onto
@@ -222,16 +296,15 @@ int runtime(Runtime** out) {
             // Streams and hardware queues.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per stream
             // priority level (default 4), and streams that share a queue run their kernels one after the other: seven lock-step
             // batches on one level = seven streams on four queues, three kernels in flight on average, 108 kb/s.
-            //  * GPU_MAX_HW_QUEUES >= 8 in the environment (the poreseq_amd package sets 12 when it is imported before the HIP runtime
-            //    starts; C callers export it themselves): every runtime's stream on the default level, a queue each — 146-147 kb/s.
+            //  * GPU_MAX_HW_QUEUES >= 8 in force (hwq_mode() above: in the environment the process started with, or exported by the
+            //    poreseq_amd package before HIP started): every runtime's stream on the default level, a queue each — 146-147 kb/s.
             //  * otherwise the streams are dealt round-robin to the device's three priority levels, not for the priorities' sake but
             //    for the 3 x 4 queues: 141 kb/s — the two or three batches on the lowest level finish ~0.8 s after the others
             //    (profiles/r03_d_sweep_forms.md).
             // (PORESEQ_ONE_PRIORITY=1 forces the default level, PORESEQ_PRIORITY_LEVELS=1 the dealing.)
             auto make_stream = [&](hipStream_t* st) {
                 static std::atomic<int> seq(0);
-                static const bool one = getenv("PORESEQ_ONE_PRIORITY") != nullptr ||
-                                        (!getenv("PORESEQ_PRIORITY_LEVELS") && getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) >= 8);
+                const bool one = hwq_mode(nullptr) == 1;
                 int lo = 0, hi = 0;
                 if (!one && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo > hi)
                     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi + seq++ % (lo - hi + 1));
@@ -431,35 +504,42 @@ static size_t device_total_bytes() {
     return tot;
 }
 
+// Memory plan of the device (309 GB on an MI355X): 27 % in three slabs for full score matrices (below), 13 % left alone (the HSA
+// runtime aborts the process when a launch finds no memory for its own needs, and hipMalloc rounds: pools that sum to 302 GB left
+// 5 GB free), 60 % to the runtimes.  What a runtime holds follows its share: the matrix pool grows 6 % past it, small forward batches
+// (k_fill) add an eighth in step words, Smith-Waterman checkpoints a quarter, and ~2.5 GB do not depend on it (remapped alignments,
+// band tables, edit tables): 1.4 x share + 2.5 GB, measured at 7, 10 and 14 batches in flight.  Share: 31 GB up to four threads,
+// 17 GB with seven batches in flight, 7.7 GB with fourteen.  It sizes the chunks of FindMutations' candidate alignments (7 MB of
+// step codes each), of Smith-Waterman batches and of the Viterbi tables.
 double device_share_bytes() {
     if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
     const size_t tot = device_total_bytes();
     if (!tot) return 32e9;
-    // (every runtime also holds a few GB outside these pools — Viterbi tables, Smith-Waterman checkpoints, band tables — and the
-    //  full score matrices of Refine-sized ScoreMutations calls live in the process-wide slabs below: 38 % of the device)
     const int nrt = std::max(4, peak_runtimes());
-    return std::max(2e9, 0.42 * (double)tot / nrt);
+    return std::max(2e9, (0.60 * (double)tot / nrt - 2.5e9) / 1.4);
 }
 
 // ---- slabs for full score matrices -----------------------------------------------------------------------------------------
 // Only a ScoreMutations call whose edit list reads most columns (Refine / ScorePoints: point edits at every position, ~4 % of a
 // consensus schedule's calls) keeps full forward + backward matrices: 265 MB per 10 kb event, 53 GB for a lock-step call of 20
 // regions.  Sizing every runtime's pools for that (round 3: 65 % of the device divided by the batches in flight) made the number of
-// batches in flight a memory question.  Instead the process keeps a few slabs (PORESEQ_SLABS, default 2, of PORESEQ_SLAB_GB,
-// default 19 % of the device each: 55 GB on an MI355X), allocated on first use and never freed; a dense call takes one for its
+// batches in flight a memory question.  Instead the process keeps a few slabs (PORESEQ_SLABS, default 3, of PORESEQ_SLAB_GB,
+// default 9 % of the device each: 28 GB on an MI355X = the matrices of 10 regions per launch), allocated on first use and never
+// freed; a dense call takes one for its
 // duration (fills, backtrace, edit scoring, read-back) and waits when all are taken.  Nothing is acquired while a slab is held.
+// A single AlignData whose matrices exceed a slab (a 48 kb region with 30 events: 41 GB) takes the calling runtime's own pools.
 namespace {
 struct Slab { char* p = nullptr; size_t bytes = 0; bool busy = false; };
 std::mutex g_slab_mu;
 std::condition_variable g_slab_cv;
 std::vector<Slab*> g_slabs;
 }  // namespace
-static int slab_count() { static const int n = getenv("PORESEQ_SLABS") ? std::max(1, atoi(getenv("PORESEQ_SLABS"))) : 2; return n; }
+static int slab_count() { static const int n = getenv("PORESEQ_SLABS") ? std::max(1, atoi(getenv("PORESEQ_SLABS"))) : 3; return n; }
 size_t slab_bytes() {
     static const double gb = getenv("PORESEQ_SLAB_GB") ? atof(getenv("PORESEQ_SLAB_GB")) : 0.0;
     if (gb > 0) return (size_t)(gb * 1e9);
     const size_t tot = device_total_bytes();
-    return tot ? (size_t)(0.19 * (double)tot) : (size_t)48e9;
+    return tot ? (size_t)(0.09 * (double)tot) : (size_t)24e9;
 }
 // bytes of full matrices one dense call may place: the slab, or PORESEQ_MAX_BATCH_GB when set (tests: tiny budgets)
 double dense_cap_bytes() {
@@ -703,8 +783,14 @@ int Align::refs_to_host(Runtime* rt) {
 // cpp/MakeMutations.cpp:148-195, and of Alignment::update with ndir == 2, cpp/Alignment.cpp:63-73)
 static int sweep_min_default() { static const int v = getenv("PORESEQ_SWEEP_MIN") ? atoi(getenv("PORESEQ_SWEEP_MIN")) : 400; return v; }
 static int sweep2_min_default() { static const int v = getenv("PORESEQ_SWEEP2_MIN") ? atoi(getenv("PORESEQ_SWEEP2_MIN")) : (1 << 30); return v; }
-// column-sparse Alignment::update (ScoreMutations whose edit list reads few columns): from this many sweeps on
-static int sparse_min_default() { static const int v = getenv("PORESEQ_SPARSE_MIN") ? atoi(getenv("PORESEQ_SPARSE_MIN")) : 160; return v; }
+// column-sparse Alignment::update (ScoreMutations whose edit list reads few columns): from this many sweeps on.  A wave per sweep
+// takes ~27 ms for a 10 kb event whatever the chip could do, a workgroup per sweep ~11-14 ms: a lone driver thread's small batches
+// (one region: 20 sweeps) finish sooner on k_fill.  With several lock-step batches in flight the chip is shared and what counts is
+// the SIMD time a sweep holds (1.6x less as a wave) and the CUs it leaves to the other batches: every size takes the sweep.
+static int sparse_min_default() {
+    static const int v = getenv("PORESEQ_SPARSE_MIN") ? atoi(getenv("PORESEQ_SPARSE_MIN")) : -1;
+    return v >= 0 ? v : (live_runtimes() > 1 ? 0 : 160);
+}
 static std::atomic<int> g_sweep_min(-1), g_sweep2_min(-1), g_sparse_min(-1);
 void sweep_min_set(int n) { g_sweep_min.store(n); }
 void sweep2_min_set(int n) { g_sweep2_min.store(n); }
@@ -1175,7 +1261,9 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     if (specs.empty()) return PS_OK;
     Batch b;
     SlabHold slab;   // full matrices: one of the process's slabs for the duration of this call (released at every return)
-    if (!sparse) {
+    double lone_need = 0;   // a single AlignData cannot be split: matrices beyond a slab go to the runtime's own pools
+    if (!sparse && R == 1) for (int e = 0; e < as[0]->E; e++) lone_need += ((double)as[0]->n[e] + as[0]->states.size() + 1 + MAT_FRONT + MAT_BACK) * std::min(1024, 2 * as[0]->par.realign_width + 74) * 36.0;
+    if (!sparse && lone_need <= (double)slab_bytes()) {
         PS_TRY(slab_acquire(&slab));
         slab.drain = rt->stream;
         b.ext = slab.p; b.ext_bytes = R > 1 ? std::min(slab.bytes, (size_t)dense_cap_bytes()) : slab.bytes;
@@ -1390,6 +1478,18 @@ int make_mutations_multi(Runtime* rt, const std::vector<Align*>& as, std::vector
         active.swap(next);
     }
     return PS_OK;
+}
+
+// one line about the process-wide state of the library (ps_info): stream / hardware-queue mode, runtimes, memory plan
+std::string info_string() {
+    std::string why;
+    (void)hwq_mode(&why);
+    size_t nslab = 0, slab_b = 0;
+    { std::lock_guard<std::mutex> lk(g_slab_mu); nslab = g_slabs.size(); for (Slab* sl : g_slabs) slab_b += sl->bytes; }
+    char buf[512];
+    snprintf(buf, sizeof buf, "; runtimes: %d live, %d peak; share per runtime %.1f GB; slabs for full score matrices: %zu of %d allocated (%.1f GB, %.1f GB each by plan); device pools of this process %.1f GB",
+             live_runtimes(), peak_runtimes(), device_share_bytes() * 1e-9, nslab, slab_count(), slab_b * 1e-9, slab_bytes() * 1e-9, (double)g_pool_bytes.load() * 1e-9);
+    return "hip-gfx950; streams: " + why + buf;
 }
 
 int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases) {

@@ -120,6 +120,8 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
                          const std::vector<std::vector<Mut>*>& outs);
 int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<RandState*>& rngs, int nkeep, double skip, double stay,
                          double mmin, double mmax, const std::vector<std::vector<std::string>*>& outs);
+std::string info_string();   // process-wide state in one line (ps_info)
+int hwq_mode(std::string* why);   // 1: every stream on one priority level (a hardware queue each), 0: streams dealt over the levels
 int peak_runtimes();   // most host threads that ever owned a runtime at the same time
 int live_runtimes();   // host threads that currently own a runtime
 int guess_slots(const Align* a);   // anti-diagonal footprint realign() will probably choose

@@ -458,15 +458,20 @@ int viterbi_device_multi(Runtime* rt, const std::vector<VitRegionH>& regions, in
     for (int r = 0; r < R; r++)
         if (regions[r].T) PS_TRY(rt->up(d_in + regs[r].in_off, regions[r].obsin, (size_t)regions[r].T * regions[r].E * 4 * sizeof(double)));
     prof_begin(rt);
-    if (maxE <= 72) {
-        static std::atomic<bool> attr(false);
-        if (!attr.load(std::memory_order_acquire)) {
-            PS_HIP(hipFuncSetAttribute((const void*)k_vit_obs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr.store(true, std::memory_order_release);
+    bool lds_ok = false;
+    if (maxE <= 72) {   // the LDS column sort needs 144 KB of dynamic LDS at 72 events: when the attribute cannot be had, the register / scratch kernels below serve
+        static std::atomic<int> attr(0);   // 0: untried, 1: granted, -1: refused
+        if (attr.load(std::memory_order_acquire) == 0) {
+            const hipError_t e = hipFuncSetAttribute((const void*)k_vit_obs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) (void)hipGetLastError();
+            attr.store(e == hipSuccess ? 1 : -1, std::memory_order_release);
         }
+        lds_ok = attr.load(std::memory_order_acquire) == 1;
+    }
+    if (lds_ok)
         hipLaunchKernelGGL(k_vit_obs_lds, dim3((unsigned)ttot), dim3(256), (size_t)256 * std::max(maxE, 1) * sizeof(double), rt->stream, d_regs, d_posreg, d_in,
                            std::log(2 * M_PI), d_obs, d_eobs);
-    } else if (maxE <= 64) hipLaunchKernelGGL(k_vit_obs<64>, dim3((unsigned)ttot), dim3(256), 0, rt->stream, d_regs, d_posreg, d_in, std::log(2 * M_PI), d_obs, d_eobs);
+    else if (maxE <= 64) hipLaunchKernelGGL(k_vit_obs<64>, dim3((unsigned)ttot), dim3(256), 0, rt->stream, d_regs, d_posreg, d_in, std::log(2 * M_PI), d_obs, d_eobs);
     else hipLaunchKernelGGL(k_vit_obs<256>, dim3((unsigned)ttot), dim3(256), 0, rt->stream, d_regs, d_posreg, d_in, std::log(2 * M_PI), d_obs, d_eobs);
     hipLaunchKernelGGL(k_vit_steps, dim3(R), dim3(1024), 0, rt->stream, d_regs, d_obs, d_eobs, skip, stay, std::log(skip), std::log(stay),
                        std::log(0.25), d_bp, d_fwd, d_lik, nkeep ? 1 : 0);

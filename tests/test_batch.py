@@ -133,10 +133,35 @@ def test_hip_seed_chunks_are_cut_again_when_the_bands_are_wider_than_guessed():
 
 
 def test_package_import_asks_hip_for_more_hardware_queues_unless_told_otherwise():
-    """poreseq_amd/__init__.py: GPU_MAX_HW_QUEUES=12 is set at import when nobody has set it (lock-step batches in flight want a hardware
-    queue each: DESIGN.md 5b); a value from the user's environment stays."""
+    """poreseq_amd/__init__.py: GPU_MAX_HW_QUEUES=16 is exported at import when nobody has set it and nothing in the process has
+    opened the GPU (lock-step batches in flight want a hardware queue each: DESIGN.md 5b), together with the flag that tells the
+    library the value is in force; a value from the user's environment stays and is not flagged."""
     import subprocess, sys
-    code = "import os, sys; sys.path.insert(0, %r); import poreseq_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % B.ROOT
-    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.check_output([sys.executable, "-c", code], env=env, timeout=300).decode().split()[-1] == "12"
-    assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="4"), timeout=300).decode().split()[-1] == "4"
+    code = ("import os, sys; sys.path.insert(0, %r); import poreseq_amd; "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), os.environ.get('PORESEQ_HWQ_SET_BY_PACKAGE'))" % B.ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "PORESEQ_HWQ_SET_BY_PACKAGE")}
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, timeout=300).decode().split()[-2:] == ["16", "1"]
+    assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="4"), timeout=300).decode().split()[-2:] == ["4", "None"]
+    # a process that has opened the GPU before the import (here: a stand-in file descriptor on /dev/kfd is not available on a CPU box,
+    # so the check itself is exercised): the package leaves the environment alone
+    code2 = ("import os, sys; sys.path.insert(0, %r); import poreseq_amd as p; "
+             "p._os.readlink = lambda path: '/dev/kfd'; p._os.environ.pop('GPU_MAX_HW_QUEUES', None); p._os.environ.pop('PORESEQ_HWQ_SET_BY_PACKAGE', None); "
+             "p._want_hw_queues(); print(os.environ.get('GPU_MAX_HW_QUEUES'), os.environ.get('PORESEQ_HWQ_SET_BY_PACKAGE'))" % B.ROOT)
+    assert subprocess.check_output([sys.executable, "-c", code2], env=env, timeout=300).decode().split()[-2:] == ["None", "None"]
+
+
+def test_library_says_how_its_streams_get_hardware_queues():
+    """ps_info (C ABI): a GPU_MAX_HW_QUEUES that appears in the environment after start-up WITHOUT the package's flag is not trusted
+    (HIP may have started before it was set: seven streams would share four queues of one priority level); the start-up environment
+    and the package's own export are."""
+    import subprocess, sys
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "%s\n"
+            "from poreseq_amd import _capi\nprint(_capi.load_hip().info())" )
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "PORESEQ_HWQ_SET_BY_PACKAGE", "PORESEQ_ONE_PRIORITY", "PORESEQ_PRIORITY_LEVELS")}
+    run = lambda pre, e: subprocess.check_output([sys.executable, "-c", code % (B.ROOT, pre)], env=e, timeout=300).decode()
+    assert "exported by the poreseq_amd package" in run("", env)
+    assert "start-up environment" in run("", dict(env, GPU_MAX_HW_QUEUES="12"))
+    late = run("os.environ['GPU_MAX_HW_QUEUES'] = '12'   # set by a host program after start-up, before the import: the package does not flag it", env)
+    assert "not trusted" in late and "dealt over the priority levels" in late
+    assert "HIP's default" in run("", dict(env, GPU_MAX_HW_QUEUES="4"))
