@@ -7,7 +7,7 @@ poreseq/Mutate.py:70-85) over one BATCH of R independent synthetic regions, each
 parallelism (one process per region file, README.md:48-54).  One GPU refines the R regions of a step as B lock-step
 batches (poreseq_amd.batch / the ps_batch_* entry points; one host thread and one stream per batch): every phase of the
 schedule is one launch chain over all of a batch's events, with the default HIP environment (no extra hardware queues,
-no per-region threads or streams).  Default: 140 regions as 7 batches of 20.
+no per-region threads or streams).  Default: 280 regions as 14 batches of 20.
 The clock covers what SURVEY.md section 8(d) defines as the metric: marshalling of the events + H2D (RegionBatch.load, the copy a
 PSAlign call does, once per region), the whole schedule incl. the host's greedy steps, and D2H of sequences and alignments; the
 synthetic data are generated outside it.  `resident` in the JSON line is the same measurement with the load left out of the
@@ -97,8 +97,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--events", type=int, default=10)
-    ap.add_argument("--regions-per-gpu", type=int, default=140, help="independent regions refined on one GPU per step")
-    ap.add_argument("--batches-in-flight", type=int, default=7,
+    ap.add_argument("--regions-per-gpu", type=int, default=280, help="independent regions refined on one GPU per step")
+    ap.add_argument("--batches-in-flight", type=int, default=14,
                     help="lock-step batches per GPU (one host thread each): while one batch is in a thin phase or on the host, "
                          "the others keep the GPU full; the regions of a step are dealt round-robin to the batches")
     ap.add_argument("--stream", action="store_true",
