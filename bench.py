@@ -286,17 +286,21 @@ def main():
     if os.environ.get("PORESEQ_TRACE"):
         sys.stderr.write("=== MEASURED RUN ===\n")       # tools/tracesum.py sums the host phases after this line
     if not args.stream:
-        dt, last = 0.0, None
+        # every step starts at a barrier: the job's time for a step is the slowest rank's, and the run's the sum of those
+        # (max over ranks of the per-rank sums would be optimistic: the slowest rank may differ from step to step)
+        dt, dt_res, last = 0.0, 0.0, None
         for regs in timed_regs:
             t, outs = run_steps([regs], timed=True)
-            dt += t
+            dt += psdist.max_over_ranks(t)
+            dt_res += psdist.max_over_ranks(t - load_s[-1])
             last = outs[-1]
+        psdist.barrier()
     else:
         dt, outs = run_steps(timed_regs, timed=True)
         last = outs[-1]
-    psdist.barrier()
-    dt_res = psdist.max_over_ranks(dt - sum(load_s))
-    dt = psdist.max_over_ranks(dt)
+        psdist.barrier()
+        dt_res = psdist.max_over_ranks(dt - sum(load_s))
+        dt = psdist.max_over_ranks(dt)
     kb = args.length / 1000.0
     value = world * R * kb * args.steps / dt
 
@@ -312,6 +316,8 @@ def main():
                                   "run step by step (a step's batches all finish before the next step's start)" if not args.stream
                                   else "stream (a slot takes the next batch when its own is done; no barrier between steps)", NB),
                    "region_bases": args.length, "events": args.events, "regions_per_gpu": R, "batches_in_flight": NB, "step_barrier": not args.stream,
+                   "not_timed_between_steps": "construction of the next step's PSAlign objects from the pre-generated synthetic regions (a deep copy of "
+                                              "the event arrays) and reading the queued HIP-event pairs of the finished step",
                    "parallelism": "%d regions x %d GPU(s), %d host thread(s) per GPU, no data-path collective" % (R, world, NB)},
     }
 

@@ -223,43 +223,73 @@ def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_e
     through the slots (bench.py: 7 slots of 20 regions on one MI355X).  Every region draws from its own random stream
     (poreseq_amd.batch), so the results do not depend on batch, in_flight or on which slot refines a region."""
     from .consensus import consensus_regions
+    from .poreseqcpp import PSAlign
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     mine = shard(regions, rank, world, weights=[b - a for a, b in regions])
+    hip_backend = False   # (decided on the first region's object: a driver over a CPU checker must not start HIP runtimes)
     step = max(1, int(batch))
     chunks = [mine[k:k + step] for k in range(0, len(mine), step)]
+
+    if mine and in_flight > 1:
+        a0, b0 = mine[0][1]
+        probe = make_region_pa(a0, b0)
+        hip_backend = isinstance(probe, PSAlign) and type(probe)._native is PSAlign._native
 
     def one(chunk):
         pas = [make_region_pa(a, b) for _, (a, b) in chunk]
         res = consensus_regions(pas, params, reps=reps)
         return [(idx, seq, np.array([acc])) for (idx, _), (seq, acc) in zip(chunk, res)]
 
-    local = [r for part in stream_batches(chunks, one, in_flight) for r in part]
+    local = [r for part in stream_batches(chunks, one, in_flight, enter=_enter_hip_library if hip_backend else None) for r in part]
     got = gather_regions(local, len(regions), max_events)
     return [(s, float(c[0])) for s, c in got]
 
 
-def stream_batches(items, work, in_flight=1):
+def _enter_hip_library():
+    """a cheap call into the HIP library: the calling thread takes its runtime (stream + device pools)"""
+    from . import _capi
+    _capi.load_hip().prof_reset()
+
+
+def stream_batches(items, work, in_flight=1, enter=None):
     """work(item) for every item on up to `in_flight` host threads; a thread takes the next item when its own is done.
-    Results in item order; the first exception is re-raised after the running items have finished."""
+    Results in item order.  On the first exception the items that have not started are cancelled, the running ones finish, and the
+    exception is re-raised.
+
+    enter: optional callable run once in every worker thread, all of them together, before the first item starts — refine_regions
+    passes a call into the HIP library, so that every worker owns its runtime before the first batch sizes its device pools (the
+    device is shared n ways from the start; a runtime that sized its pools while it was alone would hold twice its share).  Drivers
+    over another backend leave it out: nothing then touches the GPU on their behalf."""
     items = list(items)
     if in_flight <= 1 or len(items) <= 1:
         return [work(it) for it in items]
     import threading
     from concurrent.futures import ThreadPoolExecutor
     n = min(int(in_flight), len(items))
-    gate = threading.Barrier(n)
+    pool = ThreadPoolExecutor(max_workers=n)
+    try:
+        if enter is not None:
+            gate = threading.Barrier(n)
 
-    def enter(_):
-        # every worker enters the library before the first batch sizes its device pools: the device is shared n ways from the start
-        # (a runtime that sized its pools while it was alone would hold twice its share)
-        try:
-            from . import _capi
-            _capi.load_hip().prof_reset()
-        except Exception:   # (a driver over another backend: the hint is moot, the work itself reports what is wrong)
-            pass
-        gate.wait()
-
-    with ThreadPoolExecutor(max_workers=n) as pool:
-        list(pool.map(enter, range(n)))
-        return list(pool.map(work, items))
+            def enter_all(_):
+                try:
+                    enter()
+                finally:
+                    gate.wait()
+            list(pool.map(enter_all, range(n)))
+        futures = [pool.submit(work, it) for it in items]
+        out, err = [], None
+        for f in futures:
+            if err is not None:
+                f.cancel()             # (a no-op for the ones already running: they finish below)
+                continue
+            try:
+                out.append(f.result())
+            except BaseException as e:   # noqa: BLE001 — re-raised below, after the pool has drained
+                err = e
+        if err is not None:
+            raise err
+        return out
+    finally:
+        pool.shutdown(wait=True, cancel_futures=True)

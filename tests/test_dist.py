@@ -331,3 +331,34 @@ def test_stream_batches_keeps_item_order_and_reraises():
 
     with pytest.raises(ValueError, match="item 2"):
         psdist.stream_batches(range(5), bad, in_flight=2)
+
+    # after the first failure nothing new starts: of 40 slow items on two threads only the ones already running finish
+    started = []
+
+    def slow_bad(k):
+        with lock:
+            started.append(k)
+        if k == 1:
+            raise ValueError("item 1")
+        time.sleep(0.05)
+        return k
+
+    with pytest.raises(ValueError, match="item 1"):
+        psdist.stream_batches(range(40), slow_bad, in_flight=2)
+    assert len(started) < 10
+
+    # the entry hook runs once in every worker, before any item
+    entered = []
+    order = []
+
+    def enter():
+        with lock:
+            entered.append(threading.get_ident())
+
+    def work2(k):
+        with lock:
+            order.append(len(entered))
+        return k
+
+    assert psdist.stream_batches(range(6), work2, in_flight=3, enter=enter) == list(range(6))
+    assert len(entered) == 3 and len(set(entered)) == 3 and min(order) == 3
