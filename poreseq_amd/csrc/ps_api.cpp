@@ -256,10 +256,8 @@ int ps_batch_make_mutations(int32_t n, ps_align* const* a, const ps_muts* const*
     if (n && (!scored || !n_bases)) return fail(PS_ERR_BAD_ARG, "ps_batch_make_mutations");
     NEED_RT();
     std::vector<std::vector<Mut>> in(n);
-    for (int i = 0; i < n; i++) {
-        if (!scored[i]) return fail(PS_ERR_BAD_ARG, "ps_batch_make_mutations: null list");
-        in[i] = scored[i]->v;
-    }
+    for (int i = 0; i < n; i++) if (!scored[i]) return fail(PS_ERR_BAD_ARG, "ps_batch_make_mutations: null list");
+    par_for(n, [&](int i) { in[i] = scored[i]->v; });   // (a Refine list is 80 000 edits per region: the copies run side by side)
     std::vector<int> nb;
     PS_TRY(make_mutations_multi(rt, as, std::move(in), &nb));
     for (int i = 0; i < n; i++) n_bases[i] = nb[i];

@@ -14,6 +14,8 @@
 #include <functional>
 #include <numeric>
 #include <mutex>
+#include <deque>
+#include <memory>
 #include <condition_variable>
 #include <thread>
 #include <cstdio>
@@ -920,19 +922,70 @@ int realign(Runtime* rt, Batch& b, double cap) {
     return PS_OK;
 }
 
-// run fn(k) for k in [0, n) on up to 32 host threads (disjoint outputs; the GPU work of a batched call is enqueued by the caller)
+// run fn(k) for k in [0, n) on the calling thread plus helpers from a process-wide pool of host threads (disjoint outputs; the GPU
+// work of a batched call is enqueued by the caller).  The pool's threads live for the process: a lock-step schedule makes ~500 such
+// calls per batch, fourteen batches at once — creating up to 32 threads for each of them cost more than most of the loops.  Helpers
+// per call: PORESEQ_HOST_THREADS (poreseq_amd.dist.init sets it to this rank's share of the node's cores when several ranks share a
+// node), else up to 32; the pool holds twice that for callers that overlap.  A helper that is dequeued after the caller and the
+// other helpers have taken every index finds nothing to do and never touches the caller's frame.
+namespace {
+struct ParJob {
+    std::function<void(int)> fn;
+    int n = 0;
+    std::atomic<int> next{0}, done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    void run() {
+        int did = 0;
+        for (int k = next++; k < n; k = next++) { fn(k); did++; }
+        if (did && (done += did) >= n) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+    }
+};
+struct ParPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<ParJob>> q;
+    std::vector<std::thread> th;
+    int idle = 0;
+    size_t cap = 64;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            idle++;
+            cv.wait(lk, [&] { return !q.empty(); });
+            idle--;
+            std::shared_ptr<ParJob> j = q.front();
+            q.pop_front();
+            lk.unlock();
+            j->run();
+            j.reset();
+            lk.lock();
+        }
+    }
+    void submit(const std::shared_ptr<ParJob>& j, int helpers) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (int k = 0; k < helpers; k++) q.push_back(j);
+        int need = (int)q.size() - idle;   // queued tasks no waiting worker will take: new workers, up to the pool's size
+        for (; need > 0 && th.size() < cap; need--) { th.emplace_back([this] { worker(); }); th.back().detach(); }
+        cv.notify_all();
+    }
+};
+ParPool* par_pool() { static ParPool* p = new ParPool(); return p; }   // (never destroyed: its threads are detached and may outlive main)
+}  // namespace
+
 void par_for(int n, const std::function<void(int)>& fn) {
     if (n <= 1) { if (n == 1) fn(0); return; }
-    // helper threads per call: PORESEQ_HOST_THREADS (poreseq_amd.dist.init sets it to this rank's share of the node's cores when
-    // several ranks share a node), else up to 32
     static const int cap = [] { const char* e = getenv("PORESEQ_HOST_THREADS"); const int v = e ? atoi(e) : 32; return std::max(1, std::min(v, 64)); }();
     const int nth = std::min(n, cap);
-    std::atomic<int> next(0);
-    auto work = [&] { for (int k = next++; k < n; k = next++) fn(k); };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nth; t++) th.emplace_back(work);
-    work();
-    for (std::thread& x : th) x.join();
+    if (nth <= 1) { for (int k = 0; k < n; k++) fn(k); return; }
+    std::shared_ptr<ParJob> j = std::make_shared<ParJob>();
+    j->fn = fn; j->n = n;
+    ParPool* pool = par_pool();
+    pool->cap = (size_t)std::max(2 * cap, 8);
+    pool->submit(j, nth - 1);
+    j->run();
+    std::unique_lock<std::mutex> lk(j->mu);
+    j->cv.wait(lk, [&] { return j->done.load() >= n; });
 }
 
 // Slots per anti-diagonal realign() will probably need for this AlignData: footprint ~ (2W + 1) / 1.9 for about one level per base, + 9.
@@ -1173,11 +1226,13 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     Tick tk("score_mutations");
     const int R = (int)as.size();
     std::vector<EditPlan> plan(R);
-    for (int k = 0; k < R; k++) {
+    par_for(R, [&](int k) {   // (a Refine list is 80 000 edits per region: copied and sized side by side)
         *outs[k] = *muts[k];
         for (Mut& m : *outs[k]) m.score = -1e-6;
-        if (as[k]->par.scoring_width < 0) return fail(PS_ERR_BAD_ARG, "scoring_width < 0");
         plan_edits(as[k], *muts[k], &plan[k]);
+    });
+    for (int k = 0; k < R; k++) {
+        if (as[k]->par.scoring_width < 0) return fail(PS_ERR_BAD_ARG, "scoring_width < 0");
         if (plan[k].rc != PS_OK) return fail(plan[k].rc, "negative mutation start");
         if (plan[k].ncolmax > 64 && as[k]->par.scoring_width > 511) return fail(PS_ERR_UNSUPPORTED, "edit longer than 58 bases with scoring_width > 511");
     }
