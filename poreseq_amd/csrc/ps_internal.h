@@ -104,6 +104,7 @@ int runtime(Runtime** out);  // PS_ERR_NO_DEVICE when no usable GPU; never falls
 // the base realign of FindMutations — while the calling thread is the only one inside the library.  With several threads (lock-step
 // batches in flight) every runtime keeps to one stream: HIP maps streams onto 4 hardware queues by default (ps_host.cpp).
 int second_stream(Runtime* rt, hipStream_t* out);
+int live_runtimes();   // host threads that currently own a runtime (ps_host.cpp)
 
 // ---- mutation list (vector<MutInfo>/vector<MutScore>, cpp/AlignUtil.h:69-91) ----------------
 struct Mut {

@@ -329,9 +329,11 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     int maxn2 = 1;
     for (int k = 0; k < np; k++) maxn2 = std::max(maxn2, (int)in[k].second->size());
     // 4 columns per lane = 2048 per workgroup: a 10 kb pair runs as five chained workgroups, all but the last full (8 columns per
-    // lane: three, the last 44 % used, 7.8 instead of 6.6 ms per pair); PORESEQ_SW_K=8 selects the wide build (tests)
-    int K = 4;
-    if (const char* e = getenv("PORESEQ_SW_K")) K = atoi(e) == 8 ? 8 : 4;
+    // lane: three, the last 44 % used, 7.8 instead of 6.6 ms per pair).  8 columns per lane spread the row scan over twice the cells:
+    // 17 % fewer vector instructions per pair — with several lock-step batches in flight the chip is short of vector issue, not of
+    // latency, and the wide build is the faster one (bench: 189.9 against 184.5 kb/s).  PORESEQ_SW_K forces either (tests).
+    int K = live_runtimes() > 1 ? 8 : 4;
+    if (const char* e = getenv("PORESEQ_SW_K")) K = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
     const int sswidth = SWW * 64 * K;
     const int nss = (maxn2 + sswidth - 1) / sswidth;
     int64_t row_tot = 0, col_tot = 0, blk_tot = 0, out_tot = 0;
@@ -380,6 +382,7 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw0, st));
     switch (K) {
         case 4: PS_TRY(sw_run<4>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res)); break;
+        case 16: PS_TRY(sw_run<16>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res)); break;
         default: PS_TRY(sw_run<8>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res)); break;
     }
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw1, st));

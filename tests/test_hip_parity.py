@@ -207,7 +207,7 @@ def test_sw_all_strip_widths_and_super_strips_match_oracle():
     cases.append((s1 + "ACGTT", s1 + "ACGTT"))
     cases.append(("A" * 2600, "A" * 2700))                      # a whole super-strip of ties and a perfect diagonal
     want = [B.oracle_swalign(s1, s2) for s1, s2 in cases]
-    for var, val in ((None, None), ("PORESEQ_SW_K", "8")):      # the default 4-columns-per-lane build and the 8-column one
+    for var, val in (("PORESEQ_SW_K", "4"), ("PORESEQ_SW_K", "8"), ("PORESEQ_SW_K", "16")):      # the 4-, 8- and 16-columns-per-lane builds
         if var:
             os.environ[var] = val
         try:
