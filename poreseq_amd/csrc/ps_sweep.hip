@@ -105,6 +105,15 @@ __device__ __forceinline__ double wave_ror1(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// `x` where keep, else a huge negative FINITE number: only the high word is selected (0xFFEFFFFF: -1.797e308 whatever the low word
+// holds).  It stands for "no cell here" exactly as -infinity does — it loses every maximum against a real score (>= 0), against the
+// floors 0 and -1e300 and in every `>` test, adding an emission or a transition term leaves it where it is, and two of them are never
+// added — at one v_cndmask instead of two.
+__device__ __forceinline__ double keep_or_absent(double x, bool keep) {
+    const int hi = keep ? __double2hiint(x) : (int)0xFFEFFFFF;
+    return __hiloint2double(hi, __double2loint(x));
+}
+
 // One sweep.  DIR 0 / 1: forward / backward fill (cpp/Alignment.cpp:111-274 / 280-444: the backward cell adds its emission when it
 // is LEFT, so what a lane hands down and keeps for the diagonal is {main, stay + emission, main + emission}).  MODE 0
 // (ScoreAlignments): only the forward step codes and the per-strip maxima leave the chip.  MODE 1 / 2: the sweep of an
@@ -246,7 +255,10 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                 const double cSKIP = L + lsk;
                 const double cMATCH = DIR == 0 ? D + o : (rd ? deprev : 0.0);
                 const double cIGN = D + lin;
-                const double floor_s = top ? -BIG : 0.0;
+                // the stay floor of a band's first row is -1e300 (cpp/Alignment.cpp:230): a value that only ever loses.  Where the record of
+                // the cell is kept for a bit-exact comparison (MODE 1) it is -BIG itself; elsewhere -1e300 with a zero low word does
+                // the same at one select (the high word) instead of two
+                const double floor_s = MODE == 1 ? (top ? -BIG : 0.0) : __hiloint2double(top ? __double2hiint(-BIG) : 0, 0);
                 const double t1 = fmax(floor_s, cSTAY);
                 const double ns = fmax(t1, cEXT);
                 double nm = fmax(0.0, cSKIP);
@@ -254,22 +266,25 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                 nm = fmax(nm, cINS);
                 nm = fmax(nm, cIGN);
                 nm = fmax(nm, ns);
+                unsigned ss = 0u, sm = 4u;
                 if (DIR == 0) {
                     // step codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order (first candidate equal to the maximum)
-                    unsigned ss = cSTAY > floor_s ? 1u : 0u;
+                    ss = cSTAY > floor_s ? 1u : 0u;
                     ss = cEXT > t1 ? 2u : ss;
-                    unsigned sm = 4u;
                     sm = cIGN == nm ? 3u : sm;
                     sm = cINS == nm ? 2u : sm;
                     sm = cMATCH == nm ? (vd ? 1u : 7u) : sm;
                     sm = cSKIP == nm ? 0u : sm;
                     sm = nm > 0.0 ? sm : 0u;
-                    unsigned w = sm | (ss << 3) | (nm > 0.0 ? 0u : 32u) | (ns > 0.0 ? 0u : 64u);   // (every constant an inline operand)
-                    w = act ? w : 96u;
+                }
+                const double nmx = keep_or_absent(nm, act), nsx = keep_or_absent(ns, act);
+                if (DIR == 0) {
+                    // (a row outside the band carries both "score <= 0" bits — the walker stops there before it reads the step — because
+                    //  its scores are the absent-cell value; its step bits are whatever the selects left)
+                    unsigned w = sm | (ss << 3) | (nmx > 0.0 ? 0u : 32u) | (nsx > 0.0 ? 0u : 64u);   // (every constant an inline operand)
                     asm volatile("" : "+v"(w));                      // keep the byte's shift out of the selects' constants (a VGPR per shifted literal otherwise)
                     if ((r & 3) == 0) cw[r >> 2] = w; else cw[r >> 2] |= w << (8 * (r & 3));
                 }
-                const double nmx = act ? nm : NINF, nsx = act ? ns : NINF;
                 dprev = pmr;
                 pm[r] = nmx;
                 if (DIR) { deprev = pe[r]; pe[r] = nmx + o; }
@@ -288,7 +303,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                 }
                 if (DIR == 0) {
                     const bool gt = nmx > lbest;
-                    lbest = gt ? nmx : lbest;
+                    asm("v_max_f64 %0, %1, %2" : "=v"(lbest) : "v"(lbest), "v"(nmx));   // (= gt ? nmx : lbest: one v_max instead of two selects; no canonicalisation of the operands)
                     lbr = gt ? r : lbr;
                 }
                 __builtin_amdgcn_sched_barrier(0);
