@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_OF = {"fill": "k_fill", "sweep": "k_sweep", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}
+KERNEL_OF = {"fill": "k_fill", "sweep": "k_sweep", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}   # "sweep" = k_sweep (forward-only), k_sweeps (kept columns), k_sweep2 (full records)
 
 
 def _cpu_region_worker(job):
@@ -353,6 +353,10 @@ def main():
                     "all_kernel_classes_ms_per_step": {c: v[0] / max(args.steps, 1) for c, v in tot.items()}}
             # aggregate rate of the class over the wall time of the steps (launches of different batches overlap)
             roof["aggregate_alg_gbs"] = (nbytes / 1e9) / dt if dt > 0 else None
+            roof["aggregate_frac"] = roof["aggregate_alg_gbs"] / HBM_PEAK_GBS if dt > 0 else None
+            fills_b = tot["fill"][2] + tot["sweep"][2]
+            roof["fill_classes_aggregate"] = {"alg_gbs": (fills_b / 1e9) / dt if dt > 0 else None, "frac": (fills_b / 1e9) / dt / HBM_PEAK_GBS if dt > 0 else None,
+                                              "note": "both DP-fill classes (k_fill + k_sweep*) by the SURVEY 8(d) accounting over the wall time of the timed steps"}
             roof["launches_in_flight_mean"] = (ms / 1e3) / dt if dt > 0 else None
             # both DP-fill kernels by the same accounting (18 B per forward cell, 16 per backward cell): k_fill = a workgroup
             # per sweep, score matrices written (Alignment::update batches and small forward batches); k_sweep = a wavefront per sweep,
@@ -379,21 +383,43 @@ def main():
                     roof["one_batch_alone"] = {"avg_launch_ms": ims / max(il, 1), "alg_bytes_per_launch": ib / max(il, 1),
                                                "achieved": (ib / 1e9) / (ims / 1e3), "frac": (ib / 1e9) / (ims / 1e3) / HBM_PEAK_GBS,
                                                "launches": int(il)}
-            # HBM-side bytes per launch cannot be collected from inside this process: rocprofv3 --pmc on this very command
-            # (tools/pmc_bench.sh) writes profiles/r03_traffic.json; it is used only if its launch shape matches the live pass
+            # HBM-side bytes per launch and the vector-issue counters cannot be collected from inside this process: rocprofv3 --pmc on
+            # this very command (tools/pmc_round.sh) writes profiles/rNN_traffic.json and profiles/rNN_valu.json; the newest of each is
+            # used, and only if it was measured on this launch shape
+            import glob
+            shape_ok = lambda tj: (tj.get("length") == args.length and tj.get("events") == args.events and tj.get("regions_per_gpu") == R
+                                   and tj.get("batches_in_flight") == NB)
             try:
-                with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
+                path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+                rel = os.path.relpath(path, ROOT)
+                with open(path) as fh:
                     tj = json.load(fh)
-                tk = tj["kernels"].get(KERNEL_OF[dom])
-                same = (tk and tj.get("length") == args.length and tj.get("events") == args.events and tj.get("regions_per_batch") == max(1, R // NB)
-                        and abs(tk["alg_bytes_per_launch"] / roof["alg_bytes_per_launch"] - 1.0) < 0.10)
-                if same:
+                tk = tj["kernels"].get("class:" + KERNEL_OF[dom]) or tj["kernels"].get(KERNEL_OF[dom])
+                if tk and shape_ok(tj) and abs(tk.get("alg_bytes_per_launch", 0) / roof["alg_bytes_per_launch"] - 1.0) < 0.10:
                     roof["traffic"] = tk["fetch_bytes_per_launch"] + tk["write_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r03_traffic.json: " + tj.get("source", "")
+                    roof["traffic_source"] = rel + ": " + tj.get("source", "")
                     roof["schedule_traffic_gb_per_region"] = tj.get("whole_schedule", {}).get("gb_per_region")
                 else:
-                    roof["traffic_source"] = "profiles/r03_traffic.json ignored: measured on a different launch shape"
-            except (OSError, ValueError, KeyError, ZeroDivisionError):
+                    roof["traffic_source"] = rel + " ignored: measured on a different launch shape"
+            except (OSError, ValueError, KeyError, ZeroDivisionError, IndexError):
+                pass
+            # what actually bounds these kernels is FP64 vector issue (max-plus recurrences, ~45 FP64 operations per cell, 4 cycles per
+            # wave-instruction), not HBM: the share of the step the chip's vector pipes were busy, and the instructions a sweep issues
+            try:
+                path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu.json")))[-1]
+                rel = os.path.relpath(path, ROOT)
+                with open(path) as fh:
+                    vj = json.load(fh)
+                if shape_ok(vj):
+                    sk = vj.get("sweep_kernels", {})
+                    roof["valu"] = {"busy_frac": vj["valu_busy_simd_seconds_at_2p4ghz"] / (dt / max(args.steps, 1)),
+                                    "busy_simd_seconds_per_step": vj["valu_busy_simd_seconds_at_2p4ghz"],
+                                    "valu_per_cell": sk.get("insts_per_lane_cell"), "lane_insts_per_band_cell": sk.get("lane_insts_per_band_cell"),
+                                    "wave_insts_per_sweep": sk.get("wave_insts_per_sweep"), "fp64_ops_per_cell": sk.get("fp64_ops_per_cell_reference_arithmetic"),
+                                    "source": rel + " (PMC pass of this command; busy_frac = its vector-busy SIMD-seconds over THIS run's step time)"}
+                else:
+                    roof["valu"] = {"source": rel + " ignored: measured on a different launch shape"}
+            except (OSError, ValueError, KeyError, ZeroDivisionError, IndexError):
                 pass
             out["roofline"] = roof
             sched = {"fill_sweeps": (tot["fill"][3] + tot["sweep"][3]) / max(args.steps, 1), "score_items": tot["score"][3] / max(args.steps, 1)}

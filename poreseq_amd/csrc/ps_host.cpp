@@ -719,8 +719,14 @@ int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_event
     const size_t bytes = (6 + 8) * nlev * sizeof(double) + (mdl.size() + mdl8.size() + tr.size() + 2) * sizeof(double) + 256 +
                          (size_t)std::max(E, 1) * sizeof(JobOut) + 64 * 16;
     PS_HIP(hipMalloc(&slab, bytes));
+    // the slab is filled by ONE host-to-device copy: its image is assembled in pinned staging memory first (ten copies and a memset per
+    // region before: 3 000 of a bench step's copy commands)
+    char* img = (char*)rt->stage.alloc(bytes);
+    if (!img) return fail(PS_ERR_NOMEM, "hipHostMalloc (staging arena)");
+    memset(img, 0, bytes);
     char* p = (char*)slab;
     auto carve = [&](size_t b) { char* r = p; p += (b + 63) / 64 * 64; return r; };
+    auto put = [&](const void* dev, const void* src, size_t b) { if (b) memcpy(img + ((const char*)dev - (const char*)slab), src, b); };
     d_mean = (double*)carve(nlev * 8); d_stdv = (double*)carve(nlev * 8); d_lsd = (double*)carve(nlev * 8);
     d_ra = (double*)carve(nlev * 8); d_rl = (double*)carve(nlev * 8); d_ri = (double*)carve(nlev * 8);
     d_model = (double*)carve(std::max<size_t>(mdl.size(), 1) * 8); d_trans = (double*)carve(std::max<size_t>(tr.size(), 1) * 8);
@@ -728,20 +734,12 @@ int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_event
     d_model8 = (double*)carve(std::max<size_t>(mdl8.size(), 1) * 8);
     d_lev[0] = (double*)carve(4 * nlev * 8); d_lev[1] = (double*)carve(4 * nlev * 8);
     if (ntot) {
-        PS_HIP(hipMemcpyAsync(d_mean, h_mean.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipMemcpyAsync(d_stdv, h_stdv.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipMemcpyAsync(d_lsd, lsd.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipMemcpyAsync(d_ra, h_ra.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipMemcpyAsync(d_rl, h_rl.data(), ntot * 8, hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipMemcpyAsync(d_lev[0], lev.data(), 4 * ntot * 8, hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipMemcpyAsync(d_lev[1], lev.data() + 4 * ntot, 4 * ntot * 8, hipMemcpyHostToDevice, rt->stream));
+        put(d_mean, h_mean.data(), ntot * 8); put(d_stdv, h_stdv.data(), ntot * 8); put(d_lsd, lsd.data(), ntot * 8);
+        put(d_ra, h_ra.data(), ntot * 8); put(d_rl, h_rl.data(), ntot * 8);
+        put(d_lev[0], lev.data(), 4 * ntot * 8); put(d_lev[1], lev.data() + 4 * ntot, 4 * ntot * 8);
     }
-    if (E) {
-        PS_HIP(hipMemcpyAsync(d_model, mdl.data(), mdl.size() * 8, hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipMemcpyAsync(d_trans, tr.data(), tr.size() * 8, hipMemcpyHostToDevice, rt->stream));
-        PS_HIP(hipMemcpyAsync(d_model8, mdl8.data(), mdl8.size() * 8, hipMemcpyHostToDevice, rt->stream));
-    }
-    PS_HIP(hipMemsetAsync(d_out, 0, (size_t)std::max(E, 1) * sizeof(JobOut), rt->stream));
+    if (E) { put(d_model, mdl.data(), mdl.size() * 8); put(d_trans, tr.data(), tr.size() * 8); put(d_model8, mdl8.data(), mdl8.size() * 8); }
+    PS_HIP(hipMemcpyAsync(slab, img, (size_t)(p - (char*)slab), hipMemcpyHostToDevice, rt->stream));   // (d_out: zeros)
     PS_HIP(hipStreamSynchronize(rt->stream));
     // EventData::setData ends with updaterefs() (cpp/EventData.h:223)
     Batch b;
@@ -1342,7 +1340,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         dbls += (size_t)as[k]->E * std::max(p.nr0, 1) + (size_t)as[k]->E * std::max(p.M, 1) + std::max(p.M, 1) + (size_t)as[k]->E * (as[k]->states.size() + 8);
     }
     DBuf& mb = rt->buf("mutint");
-    PS_TRY(mb.ensure(ints * sizeof(int)));
+    PS_TRY(mb.ensure(ints * sizeof(int) + 64 + (size_t)R * sizeof(ScoreArgs)));
     DBuf& db = rt->buf("mutdbl");
     PS_TRY(db.ensure(dbls * sizeof(double)));
     int* dp = mb.as<int>();
@@ -1371,10 +1369,13 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         dd += (size_t)as[k]->E * sa.oldall_pitch;
         if (!p.M || !as[k]->E) { sa.njobs = 0; sa.nitems_per_job = 0; }   // nothing to score for this AlignData: its blocks leave at once
     }
-    PS_TRY(rt->up(dp, stage.data(), stage.size() * sizeof(int)));
-    DBuf& sab = rt->buf("scoreargs");
-    PS_TRY(sab.ensure((size_t)R * sizeof(ScoreArgs)));
-    PS_TRY(rt->up(sab.p, sas.data(), (size_t)R * sizeof(ScoreArgs)));
+    // the edit tables and their descriptors (ScoreArgs, behind the tables in the same buffer) in one copy
+    const size_t sa_at = (stage.size() * sizeof(int) + 63) / 64 * 64;
+    std::vector<char> blob(sa_at + (size_t)R * sizeof(ScoreArgs));
+    memcpy(blob.data(), stage.data(), stage.size() * sizeof(int));
+    memcpy(blob.data() + sa_at, sas.data(), (size_t)R * sizeof(ScoreArgs));
+    PS_TRY(rt->up(dp, blob.data(), blob.size()));
+    const ScoreArgs* d_sas = (const ScoreArgs*)((const char*)dp + sa_at);
     tk.lap("upload");
     if (tk.on) { PS_HIP(hipStreamSynchronize(rt->stream)); }
     tk.lap("realign fwd+back (rest)");
@@ -1393,7 +1394,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
             rt->prof["score"].units += (double)p.M * as[k]->E;
         }
     }
-    PS_TRY(launch_score(rt, b.d, sab.as<ScoreArgs>(), sas));
+    PS_TRY(launch_score(rt, b.d, d_sas, sas));
     std::vector<double*> dl(R, nullptr);
     for (int k = 0; k < R; k++)
         if (plan[k].M && as[k]->E) {

@@ -21,12 +21,15 @@
 // and the traceback kernel recomputes the 64 x 64 tiles its path crosses (the same row routine with one column
 // per lane, this time deriving the 4-bit step codes into LDS) — about 300 of the 25 000 tiles of a 10 kb pair.
 // The starting cell is located by recomputing only the strips whose block maximum equals the global maximum.
+#include <cstring>
+
 #include "ps_sw.h"
 
 namespace ps {
 
 constexpr int SWB = 8;    // rows per pipeline step
-constexpr int SWW = 8;    // waves per workgroup: two per SIMD keeps one pair's strips issue-balanced over several CUs
+constexpr int SWW = 8;    // waves per workgroup of the chained form: two per SIMD keeps one pair's strips issue-balanced over several CUs
+constexpr int SWW1 = 16;  // waves per workgroup of the one-workgroup-per-pair form (below)
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp_max(int v) {   // lanes without a source keep their own value
@@ -110,21 +113,27 @@ __device__ __forceinline__ unsigned sw_row(int (&G)[K], const int (&c2)[K], cons
 // release; the first wave of strip ss+1 acquires it before it reads those rows.  A workgroup takes its strip index from a
 // per-pair ticket (not from blockIdx, whose dispatch order HIP does not promise): whoever waits for strip ss-1 knows that a
 // workgroup holding that ticket started before it, so the producer is always resident or finished.
+//
+// One workgroup per pair (WW = 16 waves, K = 8 / 16 columns per lane: up to 8 192 / 16 384 columns): the whole pair is
+// ONE super-strip, its sixteen waves pipeline over rows through LDS and nobody waits on another workgroup — no boundary column in
+// global memory, no tickets, no spinning waves holding slots and registers while their producer is scheduled.  Built for the round-3
+// review's item 5, parity-tested, and slower than the chained strips where it was meant to win (see sw_launch): selected only by
+// PORESEQ_SW_FORM=one.
 constexpr int SW_SPIN_LIMIT = 1 << 22;
-template <int K>
-__global__ __launch_bounds__(64 * SWW) void k_sw_fill(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
+template <int K, int WW>
+__global__ __launch_bounds__(64 * WW) void k_sw_fill(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
                                                   int* blkmax, int* prog, int* ticket, int* res) {
     __shared__ int s_ticket;
     if (threadIdx.x == 0) s_ticket = atomicAdd(&ticket[blockIdx.y], 1);
     __syncthreads();
     const int ss = s_ticket;
     const SwPair p = pairs[blockIdx.y];
-    if (p.n1 <= 0 || p.n2 <= 0 || ss * SWW * 64 * K >= p.n2) return;
+    if (p.n1 <= 0 || p.n2 <= 0 || ss * WW * 64 * K >= p.n2) return;
     int* prog_my = prog + (int64_t)blockIdx.y * gridDim.x + ss;
-    const bool has_next = (ss + 1) * SWW * 64 * K < p.n2;   // strip ss+1 exists: it consumes this strip's last column
+    const bool has_next = (ss + 1) * WW * 64 * K < p.n2;   // strip ss+1 exists: it consumes this strip's last column
     int seen = 0;                                           // rows of strip ss-1 known to be complete
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
-    const int gw = ss * SWW + w;
+    const int gw = ss * WW + w;
     const int wfirst = gw * 64 * K;            // 0-based first column of the wave
     const bool wave_on = wfirst < p.n2;
     const int jbase = wfirst + l * K;
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(64 * SWW) void k_sw_fill(const SwPair* pairs, const
 #pragma unroll
     for (int k = 0; k < K; k++) { c2[k] = jbase + k < p.n2 ? (int)(unsigned char)s2[jbase + k] << 4 : 0; G[k] = 8 * k; bmk[k] = 0; }
     const int lane0 = l ? -(1 << 29) : 0;
-    __shared__ int hand[SWW][2][SWB];
+    __shared__ int hand[WW][2][SWB];
     // this lane's last column is column jbase + K (1-based); every 64th column is kept as a tile boundary
     const bool keeps = ((jbase + K) & 63) == 0 && jbase + K <= p.n2;
     int* csave = colsave + p.col_off + (int64_t)((jbase + K) >> 6) * (p.n1 + 1);
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(64 * SWW) void k_sw_fill(const SwPair* pairs, const
     };
     int ch_nx, bd_nx;
     fetch(0 - w, ch_nx, bd_nx);
-    for (int s = 0; s < nchunks + SWW - 1; s++) {
+    for (int s = 0; s < nchunks + WW - 1; s++) {
         const int c = s - w;
         const int ch1 = ch_nx, bd1 = bd_nx;
         fetch(c + 1, ch_nx, bd_nx);
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(64 * SWW) void k_sw_fill(const SwPair* pairs, const
                 for (int o = 32; o; o >>= 1) bm = max(bm, __shfl_xor(bm, o));
                 if (l == 0) blkmax[p.blk_off + (int64_t)q * p.ngw + gw] = bm;
                 // lane 63 of the strip's last wave stored the boundary column of these rows: release them to strip ss+1
-                if (has_next && w == SWW - 1 && l == 63) __hip_atomic_store(prog_my, iend, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (has_next && w == WW - 1 && l == 63) __hip_atomic_store(prog_my, iend, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 if (iend < p.n1) {                    // row 64(q+1) is the top boundary of block q+1
                     int* rs = rowsave + p.row_off + (int64_t)(q + 1) * p.pitch + jbase;
 #pragma unroll
@@ -307,10 +316,10 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const char
     if (l == 0) { o[0] = best; o[1] = bi; o[2] = bj; o[3] = np; o[4] = nm; }
 }
 
-template <int K>
+template <int K, int WW>
 static int sw_run(Runtime* rt, hipStream_t st, int np, int nss, const SwPair* d_pairs, const char* d_chars, int* d_row, int* d_col,
                   int* d_blk, int* d_prog, int* d_ticket, int* d_out, int* d_res) {
-    hipLaunchKernelGGL(k_sw_fill<K>, dim3(nss, np), dim3(64 * SWW), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_res);
+    hipLaunchKernelGGL((k_sw_fill<K, WW>), dim3(nss, np), dim3(64 * WW), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_res);
     PS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_sw_trace<K>, dim3(np), dim3(64), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res);
     PS_HIP(hipGetLastError());
@@ -332,16 +341,24 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     // lane: three, the last 44 % used, 7.8 instead of 6.6 ms per pair).  8 columns per lane spread the row scan over twice the cells:
     // 17 % fewer vector instructions per pair — with several lock-step batches in flight the chip is short of vector issue, not of
     // latency, and the wide build is the faster one (bench: 189.9 against 184.5 kb/s).  PORESEQ_SW_K forces either (tests).
-    int K = live_runtimes() > 1 ? 8 : 4;
+    int K = live_runtimes() > 1 ? 8 : 4, WW = SWW;
     if (const char* e = getenv("PORESEQ_SW_K")) K = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
-    const int sswidth = SWW * 64 * K;
+    // PORESEQ_SW_FORM=one: one workgroup of 16 waves per pair when the longest sequence fits 16 x 64 x K columns — no chained workgroups,
+    // nothing spins.  Measured and NOT the default: in the bench (14 lock-step batches in flight) 176.9 kb/s against 190.3 with the
+    // chained strips — a 10 kb pair keeps 10 of the 16 waves busy, holds a whole CU, and meets at a 16-wave barrier every eight rows.
+    {
+        const char* form = getenv("PORESEQ_SW_FORM");   // (a test hook that the tests change between calls of one process: read per launch)
+        const int k1 = maxn2 <= SWW1 * 64 * 8 ? 8 : (maxn2 <= SWW1 * 64 * 16 ? 16 : 0);   // (K divides 64: every 64th column is some lane's last)
+        if (form && !strcmp(form, "one") && k1) { K = k1; WW = SWW1; }
+    }
+    const int sswidth = WW * 64 * K;
     const int nss = (maxn2 + sswidth - 1) / sswidth;
     int64_t row_tot = 0, col_tot = 0, blk_tot = 0, out_tot = 0;
     for (int k = 0; k < np; k++) {
         SwPair& p = pairs[k];
         p.n1 = (int)in[k].first->size(); p.n2 = (int)in[k].second->size();
         p.nrb = std::max(1, (p.n1 + 63) / 64);
-        p.ngw = SWW * std::max(1, (p.n2 + sswidth - 1) / sswidth);
+        p.ngw = WW * std::max(1, (p.n2 + sswidth - 1) / sswidth);
         p.pitch = ((p.n2 + 3) / 4) * 4 + 4;
         p.s1_off = (int64_t)pool.size(); pool += *in[k].first;
         p.s2_off = (int64_t)pool.size(); pool += *in[k].second;
@@ -380,10 +397,17 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     PS_HIP(hipMemsetAsync(d_blk, 0, blk_tot * sizeof(int), st));   // waves beyond a pair's last column never write theirs
     PS_HIP(hipMemsetAsync(d_prog, 0, (size_t)np * (nss + 1) * sizeof(int), st));
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw0, st));
-    switch (K) {
-        case 4: PS_TRY(sw_run<4>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res)); break;
-        case 16: PS_TRY(sw_run<16>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res)); break;
-        default: PS_TRY(sw_run<8>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res)); break;
+    if (WW == SWW1) {
+        switch (K) {
+            case 8: PS_TRY((sw_run<8, SWW1>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res))); break;
+            default: PS_TRY((sw_run<16, SWW1>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res))); break;
+        }
+    } else {
+        switch (K) {
+            case 4: PS_TRY((sw_run<4, SWW>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res))); break;
+            case 16: PS_TRY((sw_run<16, SWW>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res))); break;
+            default: PS_TRY((sw_run<8, SWW>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res))); break;
+        }
     }
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw1, st));
     PS_TRY(rt->hbuf("sw_res").ensure((size_t)np * 8 * sizeof(int)));

@@ -207,7 +207,9 @@ def test_sw_all_strip_widths_and_super_strips_match_oracle():
     cases.append((s1 + "ACGTT", s1 + "ACGTT"))
     cases.append(("A" * 2600, "A" * 2700))                      # a whole super-strip of ties and a perfect diagonal
     want = [B.oracle_swalign(s1, s2) for s1, s2 in cases]
-    for var, val in (("PORESEQ_SW_K", "4"), ("PORESEQ_SW_K", "8"), ("PORESEQ_SW_K", "16")):      # the 4-, 8- and 16-columns-per-lane builds
+    # the 4-, 8- and 16-columns-per-lane builds of the chained form, and one 16-wave workgroup per pair (8 / 16 columns per lane by
+    # length; the 17 000-column case exceeds it and takes the chain)
+    for var, val in (("PORESEQ_SW_K", "4"), ("PORESEQ_SW_K", "8"), ("PORESEQ_SW_K", "16"), ("PORESEQ_SW_FORM", "one")):
         if var:
             os.environ[var] = val
         try:

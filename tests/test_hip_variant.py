@@ -126,11 +126,13 @@ def test_run_regions_in_flight_is_deterministic_and_matches_fresh_process_oracle
     assert all(np.array_equal(a[1], b[1]) for a, b in zip(ref, one[:2]))
 
 
-def test_chained_smith_waterman_strips_under_load_match_oracle():
+@pytest.mark.parametrize("form", ["chain", "one"])
+def test_chained_smith_waterman_strips_under_load_match_oracle(form, monkeypatch):
     """10 kb pairs take three chained 4096-column strips per pair (ps_sw.hip: ticket-ordered workgroups, boundary column handed over
-    through global memory).  Eight host threads run such pairs at once, next to a thread that keeps the chip busy with fills; every
-    alignment must equal the oracle's, bit for bit."""
+    through global memory) or, in the form lock-step batches use, one 16-wave workgroup per pair.  Eight host threads run such pairs
+    at once, next to a thread that keeps the chip busy with fills; every alignment must equal the oracle's, bit for bit."""
     import threading
+    monkeypatch.setenv("PORESEQ_SW_FORM", form)
     rng = np.random.default_rng(77)
     pairs = []
     for k in range(8):
