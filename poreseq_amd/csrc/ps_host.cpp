@@ -1055,16 +1055,23 @@ int score_alignments_multi(Runtime* rt, const std::vector<Align*>& as, const std
         }
         PS_TRY(rc);
     }
-    std::vector<JobOut*> outs(as.size(), nullptr);
-    for (size_t k = 0; k < as.size(); k++) {
-        as[k]->host_refs_valid = false;
-        if (as[k]->E) PS_TRY(rt->down(&outs[k], as[k]->d_out, (size_t)as[k]->E));
+    // the jobs' scores, gathered into one array on the device: one copy back instead of one per AlignData
+    for (Align* a : as) a->host_refs_valid = false;
+    double* best = nullptr;
+    {
+        DBuf& gb = rt->buf("best");
+        PS_TRY(gb.ensure(specs.size() * sizeof(double)));
+        PS_TRY(launch_gather_best(rt, b.d, gb.as<double>()));
+        PS_TRY(rt->down(&best, gb.p, specs.size()));
     }
     bool any_likes = false;
     for (size_t k = 0; k < as.size(); k++) if (likes[k]) { any_likes = true; PS_TRY(as[k]->refs_to_host_async(rt)); }
     PS_HIP(hipStreamSynchronize(rt->stream));
-    for (size_t k = 0; k < as.size(); k++)
-        for (int e = 0; e < as[k]->E; e++) scores[k][e] = std::max(outs[k][e].best, 0.0);  // Alignment::getMax, cpp/Alignment.h:127-130
+    {
+        size_t j = 0;
+        for (size_t k = 0; k < as.size(); k++)
+            for (int e = 0; e < as[k]->E; e++) scores[k][e] = std::max(best[j++], 0.0);  // Alignment::getMax, cpp/Alignment.h:127-130
+    }
     if (any_likes)
         par_for((int)as.size(), [&](int k) {
             Align* a = as[k];
@@ -1345,6 +1352,13 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     PS_TRY(db.ensure(dbls * sizeof(double)));
     int* dp = mb.as<int>();
     double* dd = db.as<double>();
+    // every AlignData's score array first, back to back: ONE device-to-host copy returns them all (a copy per region before:
+    // 20 000 of a bench step's 25 000 copy commands, ~0.2 ms each on a loaded stream)
+    double* const score0 = dd;
+    size_t score_tot = 0;
+    std::vector<size_t> score_at(R, 0);
+    for (int k = 0; k < R; k++) { score_at[k] = score_tot; score_tot += (size_t)std::max(plan[k].M, 1); }
+    dd += score_tot;
     std::vector<int> stage;
     stage.reserve(ints);
     auto push = [&](const std::vector<int>& v) { int* r = dp + stage.size(); stage.insert(stage.end(), v.begin(), v.end()); return r; };
@@ -1360,7 +1374,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         for (int q = 0; q < 4; q++) { sa.cls_items[q] = push(p.cls[q]); sa.cls_count[q] = (int)p.cls[q].size(); }
         sa.old = dd; dd += (size_t)as[k]->E * std::max(p.nr0, 1);
         sa.delta = dd; dd += (size_t)as[k]->E * std::max(p.M, 1);
-        sa.score = dd; dd += std::max(p.M, 1);
+        sa.score = score0 + score_at[k];
         // edit positions on more than a quarter of the columns: column-pair maxima of ALL columns in one coalesced pass (k_oldall)
         sa.oldall_pitch = (int64_t)as[k]->states.size() + 8;
         sa.maxS = b.maxS;
@@ -1396,9 +1410,11 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     }
     PS_TRY(launch_score(rt, b.d, d_sas, sas));
     std::vector<double*> dl(R, nullptr);
+    double* all_scores = nullptr;
+    PS_TRY(rt->down(&all_scores, score0, score_tot));
     for (int k = 0; k < R; k++)
         if (plan[k].M && as[k]->E) {
-            PS_TRY(rt->down(&sc[k], sas[k].score, (size_t)plan[k].M));
+            sc[k] = all_scores + score_at[k];
             if (delta_out && (*delta_out)[k]) PS_TRY(rt->down(&dl[k], sas[k].delta, (size_t)as[k]->E * plan[k].M));
         }
     PS_HIP(hipStreamSynchronize(rt->stream));

@@ -245,6 +245,7 @@ struct ScoreArgs {
 };
 int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs* d_sas, const std::vector<ScoreArgs>& h_sas);
 int launch_begin(Runtime* rt, const BatchD& b);
+int launch_gather_best(Runtime* rt, const BatchD& b, double* out);   // out[job] = the job's forward maxScore (JobOut.best)
 
 // Smith-Waterman (ps_sw.hip)
 int sw_device(Runtime* rt, const std::string& s1, const std::string& s2, int* score, double* accuracy,

@@ -1247,6 +1247,13 @@ __global__ void k_begin(BatchD b) {
     O->best = 0.0; O->bi = 0; O->bj = 0;
 }
 
+// out[job] = JobOut.best of every job of the batch (the results live in their AlignData's own slabs: gathered here so that one copy
+// returns them)
+__global__ void k_gather_best(BatchD b, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < b.njobs) out[j] = b.jobs[j].out->best;
+}
+
 // =================================================================================================
 // launchers
 // =================================================================================================
@@ -1389,6 +1396,13 @@ int launch_backtrace(Runtime* rt, const BatchD& b, int maxn) {
         hipLaunchKernelGGL(k_fill_like, dim3((maxn + 255) / 256, b.njobs), dim3(256), 0, rt->stream, b);
         PS_LAUNCH_CHECK();
     }
+    return PS_OK;
+}
+
+int launch_gather_best(Runtime* rt, const BatchD& b, double* out) {
+    if (!b.njobs) return PS_OK;
+    hipLaunchKernelGGL(k_gather_best, dim3((b.njobs + 255) / 256), dim3(256), 0, rt->stream, b, out);
+    PS_LAUNCH_CHECK();
     return PS_OK;
 }
 
