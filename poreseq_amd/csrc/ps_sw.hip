@@ -31,18 +31,18 @@ constexpr int SWB = 8;    // rows per pipeline step
 constexpr int SWW = 8;    // waves per workgroup of the chained form: two per SIMD keeps one pair's strips issue-balanced over several CUs
 constexpr int SWW1 = 16;  // waves per workgroup of the one-workgroup-per-pair form (below)
 
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int dpp_max(int v) {   // lanes without a source keep their own value
-    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false));
-}
-// inclusive prefix maximum over the 64 lanes of a wave
+// inclusive prefix maximum over the 64 lanes of a wave: six v_max_i32 with a DPP-shifted first operand; a lane without a source
+// (the first lanes of a row for row_shr, the rows a row_mask leaves out) is disabled for that instruction and keeps its value.
+// Written out: through __builtin_amdgcn_update_dpp the compiler emits v_mov + v_mov_dpp + v_max per step (18 instead of 6 vector
+// instructions per row: a sixth of the fill's).  The two wait states a DPP read needs after the write of its source are the s_nop 1.
 __device__ __forceinline__ int wave_scan_max(int v) {
-    v = dpp_max<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_max<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_max<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_max<0x118, 0xf>(v);   // row_shr:8
-    v = dpp_max<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
-    v = dpp_max<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
     return v;
 }
 
@@ -214,6 +214,175 @@ __global__ __launch_bounds__(64 * WW) void k_sw_fill(const SwPair* pairs, const 
     }
 }
 
+// ---- packed fill: two columns per 32-bit register --------------------------------------------------------------------
+// Scores are at most 5 x min(n1, n2): for pairs up to 13 000 bases they fit 16 bits, and gfx950's packed 16-bit integer instructions
+// (v_pk_add / sub / min / max_u16, with op_sel picking halves) work on two columns at once.  A lane owns 8 columns in four
+// registers; column k is carried as G' = H + 8 (k + 1) (unsigned: the diagonal entering the lane's first column, H + 0, stays >= 0).
+// Same recurrence, same saved rows / columns / block maxima as k_sw_fill<8, 8> — the traceback kernel reads either — at ~6.6 vector
+// instructions per cell instead of ~10: the substitution term costs one LDS load per row when the row's base is A / C / G / T (per-lane
+// tables of 13 / 4 for the four bases in LDS; any other byte takes xor / min / sub).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 pk_of(unsigned v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ unsigned un_pk(us2 v) { return __builtin_bit_cast(unsigned, v); }
+constexpr int PKK = 8;                      // columns per lane
+constexpr int SW_PK_MAXLEN = 13000;         // 5 x 13 000 + 8 x 9 + 13 < 65 536
+
+// one row; P[m] = G' of columns 2m (low half) and 2m + 1 (high half): row i - 1 on entry, row i on return.  sp[m]: 13 where the
+// column's base equals the row's, 4 elsewhere (both halves).  bl / bprev: H(i, first column - 1) / H(i - 1, first column - 1) of the wave.
+__device__ __forceinline__ void sw_row_pk(unsigned (&P)[4], const unsigned (&sp)[4], const int bl, const int bprev, const int lane8k, const int lane0) {
+    // H(i-1, lane's first column - 1): the left lane's last column of the previous row (G' = H + 8 K there)
+    const int plast = (int)(P[3] >> 16);
+    const int d0 = __builtin_amdgcn_update_dpp(bprev + 8 * PKK, plast, 0x138 /*wave_shr:1*/, 0xf, 0xf, false) - 8 * PKK;
+    us2 y[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        // G' of the column to the left, both halves: the diagonal neighbour in the same shift (its + 8 per column is the gap step's)
+        const unsigned S = m ? __builtin_amdgcn_alignbit(P[m], P[m - 1], 16) : ((P[0] << 16) | (unsigned)d0);
+        const us2 sd = pk_of(S) + pk_of(sp[m]);                                               // diagonal + substitution score (+ 8: the shift)
+        const us2 up = __builtin_elementwise_sub_sat(pk_of(P[m]), (us2){8, 8});                // above - 8 (+ 8 - 8 of the shift: the same column)
+        const us2 fl = {(unsigned short)(8 * (2 * m + 1)), (unsigned short)(8 * (2 * m + 2))};  // the floor H = 0
+        y[m] = __builtin_elementwise_max(__builtin_elementwise_max(sd, up), fl);
+    }
+    // running maximum over the lane's eight columns (the shift absorbs the gap steps)
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const us2 lo = {y[m].x, y[m].x};
+        y[m] = __builtin_elementwise_max(y[m], lo);
+        if (m) { const us2 ph = {y[m - 1].y, y[m - 1].y}; y[m] = __builtin_elementwise_max(y[m], ph); }
+    }
+    // scan of the lanes' last columns (as H + 8 K (lane + 1)); the wave's left boundary enters through lane 0 (as a lane -1)
+    int z = (int)y[3].y + lane8k;
+    z = max(z, bl + lane0);                  // lane0 = 0 in lane 0, -2^29 elsewhere
+    z = wave_scan_max(z);
+    const int hl = __builtin_amdgcn_update_dpp(bl, z, 0x138, 0xf, 0xf, false) - lane8k;   // H(i, lane's first column - 1): reaches column k as hl in the G' shift
+    const us2 hl2 = {(unsigned short)hl, (unsigned short)hl};
+#pragma unroll
+    for (int m = 0; m < 4; m++) P[m] = un_pk(__builtin_elementwise_max(y[m], hl2));
+}
+
+template <int WW>
+__global__ __launch_bounds__(64 * WW) void k_sw_fill_pk(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
+                                                       int* blkmax, int* prog, int* ticket, int* res) {
+    constexpr int K = PKK;
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ticket[blockIdx.y], 1);
+    __syncthreads();
+    const int ss = s_ticket;
+    const SwPair p = pairs[blockIdx.y];
+    if (p.n1 <= 0 || p.n2 <= 0 || ss * WW * 64 * K >= p.n2) return;
+    int* prog_my = prog + (int64_t)blockIdx.y * gridDim.x + ss;
+    const bool has_next = (ss + 1) * WW * 64 * K < p.n2;
+    int seen = 0;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int gw = ss * WW + w;
+    const int wfirst = gw * 64 * K;
+    const bool wave_on = wfirst < p.n2;
+    const int jbase = wfirst + l * K;
+    const char* s1 = chars + p.s1_off;
+    const char* s2 = chars + p.s2_off;
+    // substitution scores of the lane's eight columns against each of the four bases, in LDS: a row reads its table with one 16-byte
+    // LDS load (no vector instruction per column; tables in registers picked by a uniform branch cost 17 register moves per row)
+    __shared__ uint4 s_sp[4][64 * WW];
+    unsigned P[4], bmk[4], c2p[4];
+    {
+        unsigned tb[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const unsigned a = jbase + 2 * m < p.n2 ? (unsigned)(unsigned char)s2[jbase + 2 * m] : 0u, b = jbase + 2 * m + 1 < p.n2 ? (unsigned)(unsigned char)s2[jbase + 2 * m + 1] : 0u;
+            c2p[m] = (a << 4) | (b << 20);
+            auto tab = [&](unsigned ch) { return (a == ch ? 13u : 4u) | ((b == ch ? 13u : 4u) << 16); };
+            tb[0][m] = tab('A'); tb[1][m] = tab('C'); tb[2][m] = tab('G'); tb[3][m] = tab('T');
+            P[m] = (unsigned)(8 * (2 * m + 1)) | ((unsigned)(8 * (2 * m + 2)) << 16);
+            bmk[m] = 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) s_sp[q][threadIdx.x] = make_uint4(tb[q][0], tb[q][1], tb[q][2], tb[q][3]);
+    }
+    const int lane0 = l ? -(1 << 29) : 0, lane8k = 8 * K * l;
+    __shared__ int hand[WW][2][SWB];
+    const bool keeps = ((jbase + K) & 63) == 0 && jbase + K <= p.n2;
+    int* csave = colsave + p.col_off + (int64_t)((jbase + K) >> 6) * (p.n1 + 1);
+    const int* cprev = colsave + p.col_off + (int64_t)(wfirst >> 6) * (p.n1 + 1);
+    if (wave_on && keeps) csave[0] = 0;
+    int bprev = 0;
+    const int nchunks = (p.n1 + SWB - 1) / SWB;
+    auto fetch = [&](int c, int& ch, int& bd) {
+        ch = 1; bd = 0;
+        const int i0 = c * SWB;
+        if (w == 0 && ss > 0 && c >= 0 && c < nchunks) {
+            const int need = min(p.n1, (i0 + SWB + 63) & ~63);
+            int spins = 0;
+            for (; seen < need && spins < SW_SPIN_LIMIT; spins++) {
+                seen = __hip_atomic_load(prog_my - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen < need) __builtin_amdgcn_s_sleep(8);
+            }
+            if (seen < need && l == 0) atomicOr(&res[p.res_off + 5], 1);
+        }
+        if (wave_on && c >= 0 && c < nchunks && l < SWB && i0 + l < p.n1) {
+            ch = (int)(unsigned char)s1[i0 + l];
+            if (w == 0 && gw > 0) bd = cprev[i0 + 1 + l];
+        }
+    };
+    int ch_nx, bd_nx;
+    fetch(0 - w, ch_nx, bd_nx);
+    for (int s = 0; s < nchunks + WW - 1; s++) {
+        const int c = s - w;
+        const int ch1 = ch_nx, bd1 = bd_nx;
+        fetch(c + 1, ch_nx, bd_nx);
+        if (wave_on && c >= 0 && c < nchunks) {
+            const int i0 = c * SWB;
+            int bnd = bd1;
+            if (w > 0 && l < SWB && i0 + l < p.n1) bnd = hand[w - 1][(s - 1) & 1][l];
+#pragma unroll
+            for (int r = 0; r < SWB; r++) {
+                if (i0 + r < p.n1) {
+                    const int bl = __builtin_amdgcn_readlane(bnd, r), c1 = __builtin_amdgcn_readlane(ch1, r);   // c1: the row's base (uniform)
+                    const int bidx = c1 == 'A' ? 0 : c1 == 'C' ? 1 : c1 == 'G' ? 2 : c1 == 'T' ? 3 : -1;       // (scalar selects)
+                    unsigned sp[4];
+                    if (bidx >= 0) {
+                        const uint4 v = s_sp[bidx][threadIdx.x];
+                        sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
+                    } else {
+                        const unsigned c1p = ((unsigned)c1 << 4) | ((unsigned)c1 << 20);
+#pragma unroll
+                        for (int m = 0; m < 4; m++) sp[m] = un_pk((us2){13, 13} - __builtin_elementwise_min(pk_of(c2p[m] ^ c1p), (us2){9, 9}));
+                    }
+                    sw_row_pk(P, sp, bl, bprev, lane8k, lane0);
+                    bprev = bl;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) bmk[m] = un_pk(__builtin_elementwise_max(pk_of(bmk[m]), pk_of(P[m])));
+                    const int hlast = (int)(P[3] >> 16) - 8 * K;
+                    if (l == 63) hand[w][s & 1][r] = hlast;
+                    if (keeps) csave[i0 + r + 1] = hlast;
+                }
+            }
+            const int iend = min(i0 + SWB, p.n1);
+            if ((iend & 63) == 0 || iend == p.n1) {   // row block q complete
+                const int q = (iend - 1) >> 6;
+                int bm = 0;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    bm = max(bm, (int)(bmk[m] & 0xffffu) - 8 * (2 * m + 1));
+                    bm = max(bm, (int)(bmk[m] >> 16) - 8 * (2 * m + 2));
+                    bmk[m] = 0u;
+                }
+                for (int o = 32; o; o >>= 1) bm = max(bm, __shfl_xor(bm, o));
+                if (l == 0) blkmax[p.blk_off + (int64_t)q * p.ngw + gw] = bm;
+                if (has_next && w == WW - 1 && l == 63) __hip_atomic_store(prog_my, iend, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (iend < p.n1) {
+                    int* rs = rowsave + p.row_off + (int64_t)(q + 1) * p.pitch + jbase;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        if (jbase + 2 * m < p.n2) rs[2 * m] = (int)(P[m] & 0xffffu) - 8 * (2 * m + 1);
+                        if (jbase + 2 * m + 1 < p.n2) rs[2 * m + 1] = (int)(P[m] >> 16) - 8 * (2 * m + 2);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
 // recompute rows 64q+1 .. 64q+nrows of the strip of 64K columns that starts at 0-based column c0 (a multiple of 64); one wave
 template <int K, int MODE>
 __device__ __forceinline__ void sw_tile(const SwPair& p, const char* s1, const char* s2, const int* rowsave, const int* colsave,
@@ -316,6 +485,16 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const char
     if (l == 0) { o[0] = best; o[1] = bi; o[2] = bj; o[3] = np; o[4] = nm; }
 }
 
+// the packed fill (8 columns per lane, 8 waves) with the traceback of the 8-column build
+static int sw_run_pk(Runtime* rt, hipStream_t st, int np, int nss, const SwPair* d_pairs, const char* d_chars, int* d_row, int* d_col,
+                     int* d_blk, int* d_prog, int* d_ticket, int* d_out, int* d_res) {
+    hipLaunchKernelGGL((k_sw_fill_pk<SWW>), dim3(nss, np), dim3(64 * SWW), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_res);
+    PS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_sw_trace<8>, dim3(np), dim3(64), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
 template <int K, int WW>
 static int sw_run(Runtime* rt, hipStream_t st, int np, int nss, const SwPair* d_pairs, const char* d_chars, int* d_row, int* d_col,
                   int* d_blk, int* d_prog, int* d_ticket, int* d_out, int* d_res) {
@@ -397,7 +576,13 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     PS_HIP(hipMemsetAsync(d_blk, 0, blk_tot * sizeof(int), st));   // waves beyond a pair's last column never write theirs
     PS_HIP(hipMemsetAsync(d_prog, 0, (size_t)np * (nss + 1) * sizeof(int), st));
     if (rt->prof_on) PS_HIP(hipEventRecord(rt->sw0, st));
-    if (WW == SWW1) {
+    // the packed 16-bit fill serves the 8-column build whenever every pair's scores fit 16 bits (PORESEQ_SW_PK=0: never; tests)
+    bool packed = K == 8 && WW == SWW;
+    for (int k = 0; k < np && packed; k++) if (std::min(pairs[k].n1, pairs[k].n2) > SW_PK_MAXLEN) packed = false;
+    if (const char* e = getenv("PORESEQ_SW_PK")) if (atoi(e) == 0) packed = false;
+    if (packed) {
+        PS_TRY(sw_run_pk(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res));
+    } else if (WW == SWW1) {
         switch (K) {
             case 8: PS_TRY((sw_run<8, SWW1>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res))); break;
             default: PS_TRY((sw_run<16, SWW1>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res))); break;

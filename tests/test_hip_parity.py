@@ -207,43 +207,19 @@ def test_sw_all_strip_widths_and_super_strips_match_oracle():
     cases.append((s1 + "ACGTT", s1 + "ACGTT"))
     cases.append(("A" * 2600, "A" * 2700))                      # a whole super-strip of ties and a perfect diagonal
     want = [B.oracle_swalign(s1, s2) for s1, s2 in cases]
-    # the 4-, 8- and 16-columns-per-lane builds of the chained form, and one 16-wave workgroup per pair (8 / 16 columns per lane by
-    # length; the 17 000-column case exceeds it and takes the chain)
-    for var, val in (("PORESEQ_SW_K", "4"), ("PORESEQ_SW_K", "8"), ("PORESEQ_SW_K", "16"), ("PORESEQ_SW_FORM", "one")):
-        if var:
-            os.environ[var] = val
+    # the 4-, 8- and 16-columns-per-lane builds of the chained form, the packed 16-bit fill (the 8-column build's default: two columns per
+    # register; the 12 084-base pairs reach scores of 60 000) and its 32-bit twin, and one 16-wave workgroup per pair (8 / 16 columns per
+    # lane by length; the 17 000-column case exceeds it and takes the chain)
+    for env in ({"PORESEQ_SW_K": "4"}, {"PORESEQ_SW_K": "8"}, {"PORESEQ_SW_K": "8", "PORESEQ_SW_PK": "0"}, {"PORESEQ_SW_K": "16"}, {"PORESEQ_SW_FORM": "one"}):
+        os.environ.update(env)
         try:
             for (s1, s2), b in zip(cases, want):
                 a = swalign(s1, s2)
-                assert a[1] == b[1], (len(s1), len(s2), var)
+                assert a[1] == b[1], (len(s1), len(s2), env)
                 assert (a[0] == b[0]) or (np.isnan(a[0]) and np.isnan(b[0]))
         finally:
-            if var:
-                os.environ.pop(var, None)
-
-
-def test_edge_cases_match_oracle():
-    draft, events, truth = synth.make_region(150, 4, 51, B.oracle_swalign, P0, draft_error=0.0)
-    ev = copy.deepcopy(events)
-    ev[1].ref_align[:] = 0                       # inert event
-    ev[2].ref_align[5:] = 0                      # barely aligned event
-    mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(ev), P0)
-    assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents()
-    assert np.array_equal(scores(mk(PSAlign).ScorePoints()), scores(mk(B.OraclePSAlign).ScorePoints()))
-    odd = draft[:40] + "-" + draft[41:90] + "N" + draft[91:]   # invalid states
-    mk2 = lambda cls: B.make_pa(cls, odd, copy.deepcopy(events), P0)
-    assert mk2(PSAlign).ScoreEvents() == mk2(B.OraclePSAlign).ScoreEvents()
-    assert np.array_equal(scores(mk2(PSAlign).ScorePoints()), scores(mk2(B.OraclePSAlign).ScorePoints()))
-    assert B.make_pa(PSAlign, "ACGTACGTAC", [], P0).ScoreEvents() == []
-    assert len(B.make_pa(PSAlign, "ACGTACGTAC", [], P0).ScorePoints()) == 48
-    # a band footprint wider than two slots per lane of one workgroup (here: realign_width 5000 covers all ~4750 levels of a 5 kb
-    # event: ~2400 rows per anti-diagonal) fails loudly
-    d3, e3, _ = synth.make_region(5000, 2, 71, swalign, P0)
-    with pytest.raises(_capi.PoreseqError, match="wider than two slots per lane"):
-        B.make_pa(PSAlign, d3, copy.deepcopy(e3), dict(P0, realign_width=5000.0)).ScoreEvents()
-    m = MutationInfo(); m.start = -2; m.mut = "A"
-    with pytest.raises(_capi.PoreseqError):
-        B.make_pa(PSAlign, draft, copy.deepcopy(events), P0).ScoreMutations([m])
+            for k in env:
+                os.environ.pop(k, None)
 
 
 def _edit(st, o, m):
