@@ -1042,7 +1042,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     if ((unsigned)backind >= (unsigned)(C + 1)) backind = C;
     const int* __restrict__ lbf = b.lb + J.lb_off;    // tables the fills were made with
     const int* __restrict__ lbn = b.lb + J.lbn_off;   // after the backtrace: centres of the new columns
-    const double4* __restrict__ levf = (const double4*)J.lev[0];
+    // (the level records through a global-address-space pointer held in scalar registers: read through the job table the pointer is
+    //  generic, and a FLAT load with 64-bit address arithmetic per row step costs nine vector instructions where this costs two)
+    const PS_GLOBAL v4d* __restrict__ levf = (const PS_GLOBAL v4d*)uni_ptr(J.lev[0]);
     const double lsk = J.lsk, lst = J.lst, lex = J.lex, lin = J.lin;
 
     // band of the back column the target is combined with
@@ -1119,7 +1121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 const double D = lprev;
                 lprev = L;
                 const bool inb = mine && i >= i0 && i <= i1;
-                const double4 lv4 = levf[clampi(i, 1, n0) - 1];     // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
+                const v4d lv4 = levf[clampi(i, 1, n0) - 1];          // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
                 const double lev[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
                 const double o = emission8<FD>(mr, lev, log2pi, off);
                 const bool vd = vl && i != p0, top = i == i0;
@@ -1165,7 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 if (mine && i >= i0 && i <= i1) {
                     double nm = 0.0, ns = 0.0;
                     if (state >= 0) {
-                        const double4 lv4 = levf[i - 1];   // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
+                        const v4d lv4 = levf[i - 1];       // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
                         const double lev[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
                         const double o = emission8<FD>(mr, lev, b.log2pi, J.lik_offset);
                         const bool vl = i >= p0 && i <= p1, vd = i > p0 && i <= p1;
