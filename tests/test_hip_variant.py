@@ -101,6 +101,57 @@ def test_concurrent_regions_from_threads_match_oracle():
         assert np.array_equal(got[k], want[k])
 
 
+def test_dense_calls_queue_for_one_small_slab_and_match_alone():
+    """Full score matrices live in process-wide slabs that a dense ScoreMutations call takes for its duration (ps_host.cpp).  With ONE
+    slab of 0.3 GB (a subprocess: the slab plan is read once), four threads of lock-step Refine calls wait for each other, a batch whose
+    matrices exceed the slab is cut in halves, a single region larger than the slab takes the runtime's own pools — and every result equals
+    the single-threaded default run's."""
+    import hashlib, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import copy, hashlib, sys, threading\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "from poreseq_amd import synth, _capi\n"
+        "from poreseq_amd.batch import RegionBatch\n"
+        "from poreseq_amd.poreseqcpp import PSAlign, swalign\n"
+        "from poreseq_amd.util import DEFAULT_PARAMS\n"
+        "P = dict(DEFAULT_PARAMS, verbose=0)\n"
+        "regs = [synth.make_region(700 + 150 * k, 6, 6100 + k, swalign, P) for k in range(8)]\n"
+        "regs.append(synth.make_region(3000, 8, 6200, swalign, P))          # one region whose matrices alone exceed a 0.3 GB slab\n"
+        "def mk(k):\n"
+        "    pa = PSAlign(); pa.sequence, pa.events, pa.params = regs[k][0], copy.deepcopy(regs[k][1]), dict(P); return pa\n"
+        "out = {}\n"
+        "def work(t, ks):\n"
+        "    for rep in range(2):\n"
+        "        pas = [mk(k) for k in ks]\n"
+        "        with RegionBatch(pas) as rb:\n"
+        "            nb = rb.Refine()\n"
+        "        out[t] = [(nb[i], pa.sequence) for i, pa in enumerate(pas)]\n"
+        "nth = int(sys.argv[1])\n"
+        "groups = [[0, 1, 2], [3, 4], [5, 6, 7], [8]]\n"
+        "if nth == 1:\n"
+        "    for t, ks in enumerate(groups): work(t, ks)\n"
+        "else:\n"
+        "    th = [threading.Thread(target=work, args=(t, ks)) for t, ks in enumerate(groups)]\n"
+        "    [x.start() for x in th]; [x.join() for x in th]\n"
+        "print('DIGEST', hashlib.sha1(repr(sorted(out.items())).encode()).hexdigest())\n"
+        "print('INFO', _capi.load_hip().info())\n"
+    ) % (os.path.dirname(here), here)
+
+    def run(nth, extra):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code, str(nth)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = r.stdout.splitlines()
+        return [l for l in lines if l.startswith("DIGEST")][0], [l for l in lines if l.startswith("INFO")][0]
+
+    want, _ = run(1, {})
+    got, info = run(4, {"PORESEQ_SLABS": "1", "PORESEQ_SLAB_GB": "0.3"})
+    assert got == want
+    assert "1 of 1 allocated (0.3 GB" in info
+
+
 def test_run_regions_in_flight_is_deterministic_and_matches_fresh_process_oracle():
     """The region driver with several regions in flight per GPU: every region is the full stochastic consensus
     schedule (ViterbiMutate draws random numbers), results equal the one-at-a-time run and the oracle run of a
