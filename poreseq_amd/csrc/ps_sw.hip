@@ -260,8 +260,9 @@ __device__ __forceinline__ void sw_row_pk(unsigned (&P)[4], const unsigned (&sp)
     for (int m = 0; m < 4; m++) P[m] = un_pk(__builtin_elementwise_max(y[m], hl2));
 }
 
+// (at most 64 registers: a wave then fits beside two 224-register sweep waves on a SIMD; the compiler takes 79 when left alone)
 template <int WW>
-__global__ __launch_bounds__(64 * WW) void k_sw_fill_pk(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
+__global__ __launch_bounds__(64 * WW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sw_fill_pk(const SwPair* pairs, const char* chars, int* rowsave, int* colsave,
                                                        int* blkmax, int* prog, int* ticket, int* res) {
     constexpr int K = PKK;
     __shared__ int s_ticket;
@@ -412,7 +413,7 @@ __device__ __forceinline__ void sw_tile(const SwPair& p, const char* s1, const c
 
 // ---- locate the starting cell, then trace back; grid (pairs), block 64 ------------------------------------------
 template <int K>
-__global__ __launch_bounds__(64) void k_sw_trace(const SwPair* pairs, const char* chars, const int* rowsave, const int* colsave,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 8 : 4, 8))) void k_sw_trace(const SwPair* pairs, const char* chars, const int* rowsave, const int* colsave,
                                                  const int* blkmax, int* out, int* res) {
     __shared__ unsigned char codes[64][64];
     const SwPair p = pairs[blockIdx.x];
