@@ -220,7 +220,7 @@ def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_e
 
     in_flight > 1 keeps that many lock-step batches on the GPU at once, one host thread (slot) each — the library gives every
     thread its own stream and device pools, and a slot takes the next batch when its own is done, so a rank's regions stream
-    through the slots (bench.py: 7 slots of 20 regions on one MI355X).  Every region draws from its own random stream
+    through the slots (bench.py: 14 slots of 20 regions on one MI355X).  Every region draws from its own random stream
     (poreseq_amd.batch), so the results do not depend on batch, in_flight or on which slot refines a region."""
     from .consensus import consensus_regions
     from .poreseqcpp import PSAlign
