@@ -72,10 +72,20 @@ def test_hip_lock_step_equals_oracle_region_by_region():
 
 
 @pytest.mark.gpu
-def test_hip_lock_step_equals_hip_single_at_3kb():
-    """eight 3 kb regions (bands narrower than the columns, several seed-batch chunks) against the single-region path"""
+@pytest.mark.parametrize("kept_columns", ["default", "always", "never"])
+def test_hip_lock_step_equals_hip_single_at_3kb(kept_columns):
+    """eight 3 kb regions (bands narrower than the columns, several seed-batch chunks) against the single-region path; with the
+    kept-column sweeps (k_sweeps) for every ScoreMutations call whose edit lists allow it — regions of different lengths and edit lists
+    share one launch, each with its own table of kept columns — for none, and with the default thresholds"""
+    from poreseq_amd import _capi
+    api = _capi.load_hip()
     regs = _regions([(3000, 10)] * 3 + [(2500, 8), (1500, 10), (3000, 6), (800, 10), (2000, 9)], 7300, swalign)
-    _same(_one_by_one(PSAlign, regs, P), _lock_step(PSAlign, regs, P))
+    want = _one_by_one(PSAlign, regs, P)
+    api.set_sparse_min({"default": -1, "always": 0, "never": 1 << 30}[kept_columns])
+    try:
+        _same(want, _lock_step(PSAlign, regs, P))
+    finally:
+        api.set_sparse_min(-1)
 
 
 @pytest.mark.gpu
