@@ -206,6 +206,12 @@ int ps_set_sweep2_min(int32_t min_sweeps);
  * {main, stay} records of the columns scoreMutation / columnMax will read (cpp/Alignment.cpp:447-512, cpp/Alignment.h:181-214) and
  * nothing else of the score matrices.  Negative: the default (PORESEQ_SPARSE_MIN, else 160).  Results do not depend on it. */
 int ps_set_sparse_min(int32_t min_sweeps);
+/* The form every strip sweep tries first: `rows_per_lane` rows of the band per lane on `wavefronts` (1, 2 or 4) wavefronts per
+ * (alignment, direction) — ps_sweep.hip / ps_sweepw.hip; a band too wide for it takes the next larger form.  rows_per_lane <= 0 with
+ * wavefronts 1 / 2 / 4: that many wavefronts, the smallest strip height whose band fits; both <= 0: the library's own choice (by
+ * launch size; PORESEQ_SWEEP_FORM=K,NW).  Returns PS_ERR_BAD_ARG for a form that is not built.
+ * Results do not depend on it (the reference has one serial loop per alignment, cpp/Alignment.cpp:83-99). */
+int ps_set_sweep_form(int32_t rows_per_lane, int32_t wavefronts);
 
 /* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
  * algorithmic bytes of the named kernel class ("fill" = k_fill, "sweep" = k_sweep / k_sweep2, "score", "viterbi", "sw") since reset. */

@@ -23,10 +23,11 @@ int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* sta
     PS_HIP(hipMemcpyAsync(&o, a->d_out + ev, sizeof(o), hipMemcpyDeviceToHost, rt->stream));
     std::vector<int> lb(J.lbn);
     PS_HIP(hipMemcpyAsync(lb.data(), b.d.lb + J.lb_off, J.lbn * sizeof(int), hipMemcpyDeviceToHost, rt->stream));
-    // skewed matrices of k_fill (REC[i + j][i mod P], u16 step words) or strip matrices of k_sweep2 (REC[j + q][r][q mod 64], one code byte per cell)
+    // skewed matrices of k_fill (REC[i + j][i mod P], u16 step words) or strip matrices of k_sweep2 (REC[j + q][r][q mod NL], one code byte per cell)
     const int K = J.K;
     const SweepJob sj0 = K ? b.sjobs[0] : SweepJob();
-    const size_t ncell = K ? (size_t)sj0.T * 64 * K : (size_t)J.S * P;
+    const int NL = K ? J.NL : 64;   // lanes of a strip sweep (64 per wavefront)
+    const size_t ncell = K ? (size_t)sj0.T * NL * K : (size_t)J.S * P;
     std::vector<double2> rec(ncell);
     std::vector<unsigned short> flg(K ? 0 : ncell);
     std::vector<unsigned char> codes(K ? ncell : 0);
@@ -48,13 +49,13 @@ int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* sta
             const size_t to = (size_t)i * ld + c;
             if (K) {
                 const int q = (i - 1) / K, r = (i - 1) % K;
-                const size_t at = ((size_t)(c + q) * K + r) * 64 + (q & 63);
+                const size_t at = ((size_t)(c + q) * K + r) * NL + (q & (NL - 1));
                 main[to] = rec[at].x;
                 if (stay) stay[to] = rec[at].y;
                 if (dir == 0 && (sm || ss)) {
                     int r0 = 0, off = 0;
-                    for (;;) { const int sz = plane_sz(K - r0); if (r < r0 + sz) { off = 64 * r0 + (q & 63) * sz + (r - r0); break; } r0 += sz; }
-                    const unsigned by = codes[(size_t)(c + q) * 64 * K + off];
+                    for (;;) { const int sz = plane_sz(K - r0); if (r < r0 + sz) { off = NL * r0 + (q & (NL - 1)) * sz + (r - r0); break; } r0 += sz; }
+                    const unsigned by = codes[(size_t)(c + q) * NL * K + off];
                     if (sm) sm[to] = (uint8_t)((by & 7) == 7 ? 255 : (by & 7));
                     if (ss) ss[to] = (uint8_t)(((by >> 3) & 3) ? 3 + ((by >> 3) & 3) : 0);
                 }

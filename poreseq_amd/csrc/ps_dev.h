@@ -36,14 +36,14 @@ __device__ __forceinline__ void band_of(const int* __restrict__ lb, int dir, int
 
 
 // index of cell (row i, column j) of a job's forward (dir 0) / backward (dir 1) matrix in the record pool: skewed storage
-// REC[i + j][i mod P] (k_fill), strip storage REC[j + q][r][q mod 64] with q = (i - 1) / K, r = (i - 1) mod K (k_sweep2), or
+// REC[i + j][i mod P] (k_fill), strip storage REC[j + q][r][q mod NL] with q = (i - 1) / K, r = (i - 1) mod K (k_sweep2), or
 // column-sparse storage REC[kept index of column j][i - i0] (k_sweeps; i0 = first row of the column's band, which every reader has
 // at hand; only kept columns and rows inside their band exist)
 __device__ __forceinline__ int64_t rec_index(const JobD& J, int dir, int i, int j, int i0) {
     if (J.K < 0) return J.mat_off[dir] + (int64_t)J.keep[dir][j] * J.pitch + (i - i0);
     if (J.K) {
         const int q = (i - 1) / J.K, r = (i - 1) - q * J.K;
-        return J.mat_off[dir] + ((int64_t)(j + q) * J.K + r) * 64 + (q & 63);
+        return J.mat_off[dir] + ((int64_t)(j + q) * J.K + r) * J.NL + (q & (J.NL - 1));
     }
     return J.mat_off[dir] + (int64_t)(i + j) * J.P + i % J.P;
 }

@@ -801,34 +801,66 @@ bool sweep_enabled() { static const bool off = getenv("PORESEQ_NO_SWEEP") != nul
 // device bytes one forward-only job of AlignData a (n0 levels against C states) will probably take: step codes of a strip sweep,
 // or the skewed {record, step word} matrix of k_fill
 double fwd_job_bytes(const Align* a, int n0, int C) {
-    int K = sweep_enabled() ? sweep_guess_k(a->par.realign_width) : 0;
+    SweepForm f;
+    if (sweep_enabled()) f = sweep_guess_form(a->par.realign_width, 1);
     static const int dbg = getenv("PORESEQ_DEBUG_SWEEP_K") ? atoi(getenv("PORESEQ_DEBUG_SWEEP_K")) : 0;   // tests: a wrong guess
-    if (K && dbg > 0) K = dbg;
-    if (K) return sweep_job_bytes(n0, C, K);
+    if (f.ok() && dbg > 0) f.K = dbg;
+    if (f.ok()) return 1.15 * sweep_job_bytes(n0, C, f);   // (the multi-wavefront forms take up to a tenth more: more steps, fewer rows per lane)
     return ((double)n0 + C + 1 + MAT_FRONT + MAT_BACK) * guess_slots(a) * 18.0;
 }
 
-// Strip sweeps (ps_sweep.hip): one wave per alignment and direction.  Forward-only batches (ScoreAlignments) keep one byte per
-// cell; Alignment::update batches (ndir == 2, ScoreMutations) also the {main, stay} records of both directions, in strip order.
-// Returns -1 when the batch has to take the k_fill path instead (band too wide for 64 strips of any supported height).
+// Which form a strip-sweep launch takes (ps_sweep.hip: K rows per lane on NW wavefronts per sweep).  Forced by
+// ps_set_sweep_form / PORESEQ_SWEEP_FORM=K,NW (tests, tuning); else by the launch's size: a wavefront alone on its SIMD issues one
+// vector instruction per ~5 cycles whatever the chip could do, so a launch that cannot fill the chip's SIMDs with one wavefront per
+// sweep spreads every sweep over two or four.
+static std::atomic<int> g_form_K(0), g_form_NW(0);
+void sweep_form_set(int K, int NW) { g_form_K.store(K); g_form_NW.store(NW); }
+static SweepForm pick_form(int W, int nsweeps, bool fastdiv) {
+    SweepForm f;
+    int fk = g_form_K.load(), fnw = g_form_NW.load();
+    if (fk <= 0) {
+        static const char* e = getenv("PORESEQ_SWEEP_FORM");
+        if (e && sscanf(e, "%d,%d", &fk, &fnw) != 2) fk = 0;
+    }
+    if (fk > 0 && sweep_form_exists(fk, fnw) && (fnw == 1 || fastdiv)) { f.K = fk; f.NW = fnw; return f; }
+    if (fk <= 0 && (fnw == 1 || fnw == 2 || fnw == 4)) {         // only the wavefronts per sweep are given: the smallest strip height that fits
+        for (int nw = fastdiv ? fnw : 1; nw >= 1; nw >>= 1) { f = sweep_guess_form(W, nw); if (f.ok()) return f; }
+        return f;
+    }
+    static const int nw_env = getenv("PORESEQ_SWEEP_NW") ? atoi(getenv("PORESEQ_SWEEP_NW")) : 0;       // tuning: wavefronts per sweep
+    static const int w4_max = getenv("PORESEQ_SWEEP_W4_MAX") ? atoi(getenv("PORESEQ_SWEEP_W4_MAX")) : 192;   // sweeps per launch up to which four wavefronts each pay
+    int nw = nw_env > 0 ? nw_env : (nsweeps <= w4_max ? 4 : 2);
+    if (!fastdiv) nw = 1;                                         // (the multi-wavefront builds exist with tabulated reciprocals only)
+    for (; nw >= 1; nw >>= 1) {
+        f = sweep_guess_form(W, nw);
+        // a narrow band on many wavefronts leaves most lanes without a strip: at least half of them busy, else fewer wavefronts
+        if (f.ok() && (nw == 1 || ((2 * W + 1) / (f.K + 1) + 3) * 2 >= 64 * nw)) return f;
+    }
+    return sweep_guess_form(W, 1);
+}
+
+// Strip sweeps (ps_sweep.hip): one to four wavefronts per alignment and direction.  Forward-only batches (ScoreAlignments) keep one
+// byte per cell; Alignment::update batches (ndir == 2, ScoreMutations) also the {main, stay} records of both directions, in strip
+// order or of the kept columns only.  Returns -1 when the batch has to take the k_fill path instead (band too wide for any form).
 static int realign_sweep(Runtime* rt, Batch& b, double cap) {
     int W = 0;
     for (const JobD& j : b.jobs) W = std::max(W, j.W);
-    int K = sweep_guess_k(W);
-    if (const char* e = getenv("PORESEQ_DEBUG_SWEEP_K")) K = atoi(e);   // tests: a given strip height first
-    if (!K) return -1;
+    SweepForm f = pick_form(W, b.d.njobs * b.ndir, b.d.fastdiv != 0);
+    if (const char* e = getenv("PORESEQ_DEBUG_SWEEP_K")) { f.K = atoi(e); f.NW = 1; }   // tests: a given strip height first
+    if (!f.ok()) return -1;
     PS_TRY(launch_begin(rt, b.d));
     PS_TRY(launch_lb(rt, b.d, 0, b.maxlbn));
     for (;;) {
-        PS_TRY(sweep_prepare(rt, b, K));
+        PS_TRY(sweep_prepare(rt, b, f));
         int* w = nullptr;
         PS_TRY(rt->down(&w, b.sd.maxwin, (size_t)1));
         PS_HIP(hipStreamSynchronize(rt->stream));
-        { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign (strip sweep%s): %d jobs x %d, K = %d, widest window %d strips\n", b.sparse ? ", kept columns" : "", b.d.njobs, b.ndir, K, *w); }
-        if (*w <= sweep_win_max()) break;
-        K = sweep_next_k(K);
-        if (!K) { for (JobD& j : b.jobs) j.K = 0; return -1; }
+        { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] realign (strip sweep%s): %d jobs x %d, K = %d on %d wavefronts, widest window %d strips\n", b.sparse ? ", kept columns" : "", b.d.njobs, b.ndir, f.K, f.NW, *w); }
+        if (*w <= sweep_win_max(f.NW)) break;
+        f = sweep_next_form(f, *w);
+        if (!f.ok()) { for (JobD& j : b.jobs) j.K = 0; return -1; }
     }
+    const int K = f.K;
     const double bytes = (double)b.sweep_code_bytes + 16.0 * (double)b.sweep_recs;
     if (cap > 0 && bytes > cap) {
         static const bool trace = getenv("PORESEQ_TRACE") != nullptr;
@@ -1258,7 +1290,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         if (!K) sparse = false;
         njobs_all += a->E;
         for (int e = 0; e < a->E && sparse; e++)
-            sparse_bytes += sweep_job_bytes(a->n[e], C, K) + 16.0 * (plan[k].nkeep[0] + plan[k].nkeep[1]) * (std::min(2 * a->par.realign_width + 1, a->n[e]) + 3);
+            sparse_bytes += 1.15 * sweep_job_bytes(a->n[e], C, sweep_guess_form(a->par.realign_width, 1)) + 16.0 * (plan[k].nkeep[0] + plan[k].nkeep[1]) * (std::min(2 * a->par.realign_width + 1, a->n[e]) + 3);
     }
     if (sparse && 2 * njobs_all < sparse_min()) sparse = false;
     if (tk.on) {

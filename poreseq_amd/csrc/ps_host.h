@@ -48,7 +48,7 @@ struct Batch {
     // strip sweeps (forward-only batches, ps_sweep.hip)
     std::vector<SweepJob> sjobs;
     SweepD sd;
-    int sweep_K = 0, sweep_maxT = 0;
+    int sweep_K = 0, sweep_NW = 1, sweep_maxT = 0;
     int64_t sweep_code_bytes = 0, sweep_sb = 0, sweep_recs = 0;
     bool sparse = false;          // ndir == 2: records of the kept columns only (JobSpec.keep)
     char* ext = nullptr;          // full matrices go here (a slab) instead of the runtime's own pools
@@ -95,12 +95,16 @@ std::vector<int> states_of(const std::string& bases);
 std::string apply_edit(const std::string& b, const Mut& m);
 void accumulate_likes(const double* ra, const double* rl, int n, int C, double* likes);
 
-// strip sweeps (ps_sweep.hip)
-int sweep_guess_k(int W);                         // strip height to try first for realign_width W (0: too wide for a strip sweep)
-int sweep_next_k(int K);                          // next larger one (0: none)
-int sweep_win_max();                              // widest window of strips a sweep supports
-double sweep_job_bytes(int n0, int C, int K, bool full = false);   // bytes of one job: step codes (+ both directions' records)
-int sweep_prepare(Runtime* rt, Batch& b, int K);  // band / qlo tables + the widest window (b.sd.maxwin, device)
+// strip sweeps (ps_sweep.hip, ps_sweepw.hip): K rows per lane on NW wavefronts per sweep
+struct SweepForm { int K = 0, NW = 1; bool ok() const { return K > 0; } };
+int sweep_guess_k(int W);                         // strip height of the one-wavefront form for realign_width W (0: too wide for a strip sweep)
+SweepForm sweep_guess_form(int W, int NW);        // form to try first on NW wavefronts (K = 0: none)
+SweepForm sweep_next_form(SweepForm f, int win);  // next larger one after a window of `win` strips did not fit (K = 0: none)
+bool sweep_form_exists(int K, int NW);
+int sweep_win_max(int NW);                        // widest window of strips a sweep on NW wavefronts supports
+double sweep_job_bytes(int n0, int C, SweepForm f, bool full = false);   // bytes of one job: step codes (+ both directions' records)
+int sweep_prepare(Runtime* rt, Batch& b, SweepForm f);  // band / qlo tables + the widest window (b.sd.maxwin, device)
+void sweep_form_set(int K, int NW);               // tests / tuning: the form every strip sweep tries first (K <= 0: the library's choice)
 int sweep_run(Runtime* rt, Batch& b);             // sweeps, maxima, backtrace, path scores (b.sd.codes placed by the caller)
 void sweep_min_set(int n);                        // forward-only batches of at least n alignments take the strip sweep (< 0: default)
 void sweep2_min_set(int n);                       // the same for Alignment::update batches (sweeps = 2 per alignment)

@@ -133,6 +133,7 @@ struct JobD {
     int K;           // 0: skewed matrices (k_fill); > 0: strip matrices of K rows per lane (k_sweep2): REC[step][row of the strip][lane];
                      // < 0: column-sparse records (k_sweeps): only the columns an edit list reads, REC[kept column][row - band start]
     int pitch;       // column-sparse records: records per kept column (>= rows of the widest band)
+    int NL;          // strip matrices: lanes of a sweep (64 per wavefront of its workgroup); strip q sits on lane q mod NL
     const int* keep[2];  // column-sparse records: per direction, kept-column index of column j (0 .. C + 1) or -1
     int64_t lb_off;      // lb table the fills were made with          (int32[lbn])
     int64_t lbn_off;     // lb table after the latest backtrace        (int32[lbn])
@@ -186,7 +187,7 @@ struct BatchD {
 // ---- strip sweeps (ps_sweep.hip): forward-only alignments, one wave per job ------------------------
 struct StripBest;
 struct SweepJob {           // per job, parallel to BatchD.jobs
-    int64_t codes_off;      // bytes into the code pool: step t of the job starts at codes_off + t * 64 * K
+    int64_t codes_off;      // bytes into the code pool: step t of the job starts at codes_off + t * NL * K
     int64_t band_off;       // into band (int2 {i0, i1} per column, C + 2 entries)
     int64_t q_off;          // into qlo (int per step, T + 8 entries)
     int64_t sb_off;         // into the per-strip maxima (Q entries)
@@ -202,6 +203,7 @@ struct SweepD {
     StripBest* sb;
     int* maxwin;            // widest window of strips in band on one step, over the batch
     int K;
+    int nl;                 // lanes of a sweep: 64 per wavefront (ps_sweepw.hip: two or four wavefronts per sweep)
     int ndir;               // 1: forward-only jobs; 2: sweep job jd = 2 * job + direction
     int sparse;             // ndir == 2: records of the kept columns only (JobD.keep) instead of every cell's
 };

@@ -918,8 +918,8 @@ __global__ __launch_bounds__(256) void k_oldall(BatchD b, const ScoreArgs* __res
     }
 }
 
-// The same pass over strip matrices (k_sweep2): the forward records of one step t and strip row r are 64 consecutive records
-// (one per lane = strip); their partners in the backward matrix are 64 consecutive records too, in reverse order (row n0 - i + 1 of
+// The same pass over strip matrices (k_sweep2): the forward records of one step t and strip row r are NL consecutive records
+// (one per lane = strip; NL = 64 per wavefront of a sweep); their partners in the backward matrix are 64 consecutive records too, in reverse order (row n0 - i + 1 of
 // backward column C - j + 1: strip and step move by one per lane in opposite senses).  grid (ceil(maxT / OA_ST), njobs, regions), block 256.
 constexpr int OA_ST = 16;      // steps per block
 __global__ __launch_bounds__(256) void k_oldall_s(BatchD b, const ScoreArgs* __restrict__ A) {
@@ -958,12 +958,13 @@ __global__ __launch_bounds__(256) void k_oldall_s(BatchD b, const ScoreArgs* __r
     const int jbase = s_jbase;
     const double2* __restrict__ rf = b.rec + J.mat_off[0];
     unsigned long long* gmax = (unsigned long long*)(a.oldall + (size_t)blockIdx.y * a.oldall_pitch);
-    const int lane = threadIdx.x & 63;
-    for (int p = threadIdx.x >> 6; p < nst * K; p += 4) {
-        const int t = t0 + p / K, r = p % K;
+    const int NL = J.NL, NWV = NL >> 6;                                  // lanes of a sweep, 64 per wavefront
+    for (int p = threadIdx.x >> 6; p < nst * K * NWV; p += 4) {
+        const int t = t0 + p / (K * NWV), r = (p / NWV) % K;
+        const int lane = (p % NWV) * 64 + (threadIdx.x & 63);
         const int ql = __builtin_amdgcn_readfirstlane(QL[t]);
         if (ql < 0) continue;
-        const int q = ql + ((lane - ql) & 63);
+        const int q = ql + ((lane - ql) & (NL - 1));
         const int i = q * K + 1 + r, j = t - q;
         if (j < 1 || j > C || i > n0) continue;
         const int2 bf = bandF[j];
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(256) void k_oldall_s(BatchD b, const ScoreArgs* __r
         const int ib = n0 - i + 1, cb = C - j + 1;                      // partner cell in backward coordinates
         const int2 bb = bandB[cb];
         if (ib < bb.x || ib > bb.y) continue;                           // partner outside the backward band
-        const double2 fv = rf[((int64_t)t * K + r) * 64 + lane];
+        const double2 fv = rf[((int64_t)t * K + r) * NL + lane];
         const double2 bv = b.rec[rec_index(J, 1, ib, cb, bb.x)];
         const double v = fmax(fv.x + bv.x, fv.y + bv.y);
         if (v > 0.0) {

@@ -9,6 +9,7 @@
 //                                                              k_like_a / k_like_b: the scores along the path, recomputed)
 //
 // Geometry.  Rows (levels) are cut into strips of K consecutive rows; strip q = rows qK+1 .. qK+K.  Lane (q mod 64) of the wave
+// (ps_sweepw.hip: lane q mod 128 / 256 of a workgroup of two / four waves, the cross-wave neighbour through LDS)
 // owns strip q and walks it one column per step, K cells top to bottom; strip q works on column j at step t = j + q, so the
 // lane one up finished the same column one step earlier: the cell above a strip's first row arrives by one wave-rotate DPP move
 // of {main, stay}, the rest of a column's vertical dependencies are the lane's own registers.  No LDS, no barrier, no other
@@ -23,29 +24,9 @@
 // per strip.  No score matrix: the scores along the backtrace path (ref_like) are recomputed afterwards.  A cell on the path
 // equals its predecessor's score plus the move's terms (cpp/Alignment.cpp:196-237), with the very operations the fill used, so a
 // serial pass along the path (k_like_b: one wave per job, ~3 dependent additions per level) reproduces them bit for bit.
-#include "ps_dev.h"
-#include "ps_host.h"
+#include "ps_sweep_body.h"
 
 namespace ps {
-
-// ---- byte layout of one step's codes: row groups ("planes") of 16 / 8 / 4 / 2 / 1 rows, each [64 lanes][rows of the group] ----
-__host__ __device__ constexpr int plane_sz(int rem) { return rem >= 16 ? 16 : rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1; }
-template <int K>
-__device__ __forceinline__ int code_off(int lane, int r) {
-    int r0 = 0;
-#pragma unroll
-    for (int g = 0; g < 8; g++) {
-        const int sz = plane_sz(K - r0);
-        if (r < r0 + sz) return 64 * r0 + lane * sz + (r - r0);
-        r0 += sz;
-        if (r0 >= K) break;
-    }
-    return 0;
-}
-
-struct StripBest { double v; int i, j; };
-constexpr int Q_PAD = 8;          // qlo entries behind T (all -1): the sweep looks two steps ahead
-constexpr int WIN_MAX = 62;       // strips in band on one step: two lanes stay idle (a lane is never handed its next strip in the step it leaves one)
 
 // ------------------------------------------------------------------------------------------------
 // band[j] = {i0(j), i1(j)} for j = 0 .. C + 1: column 0 is the blank column covering rows 0 .. n0 (cpp/Alignment.cpp:42),
@@ -95,304 +76,40 @@ __global__ __launch_bounds__(256) void k_qlo(BatchD b, SweepD sw) {
     if ((threadIdx.x & 63) == 0 && win > 0) atomicMax(sw.maxwin, win);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_sweep: one wave per job
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_ror1(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C /*wave_ror:1*/, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-// `x` where keep, else a huge negative FINITE number: only the high word is selected (0xFFEFFFFF: -1.797e308 whatever the low word
-// holds).  It stands for "no cell here" exactly as -infinity does — it loses every maximum against a real score (>= 0), against the
-// floors 0 and -1e300 and in every `>` test, adding an emission or a transition term leaves it where it is, and two of them are never
-// added — at one v_cndmask instead of two.
-__device__ __forceinline__ double keep_or_absent(double x, bool keep) {
-    const int hi = keep ? __double2hiint(x) : (int)0xFFEFFFFF;
-    return __hiloint2double(hi, __double2loint(x));
-}
-
-// One sweep.  DIR 0 / 1: forward / backward fill (cpp/Alignment.cpp:111-274 / 280-444: the backward cell adds its emission when it
-// is LEFT, so what a lane hands down and keeps for the diagonal is {main, stay + emission, main + emission}).  MODE 0
-// (ScoreAlignments): only the forward step codes and the per-strip maxima leave the chip.  MODE 1 / 2: the sweep of an
-// Alignment::update (ScoreMutations) — also the per-column maxima (MaxInfo, cpp/Alignment.cpp:158, 270) through a 256-column LDS
-// ring to cmax, and {main, stay} records: of every cell, REC[step][row of the strip][lane] (MODE 1: one coalesced 1 KB store per
-// row and step), or only of the columns the edit list will read (MODE 2: scoreMutation / columnMax, cpp/Alignment.cpp:447-512,
-// cpp/Alignment.h:181-214, read the forward columns max(start-4, 0) and max(start-3, 1) and two backward columns per edit): the
-// lane whose column is kept (JobD.keep, fetched with the band record) writes its in-band cells to REC[kept column][row - i0].
-constexpr int RING = 256;       // columns of the maxima ring: the window's 62 + the 64 steps between two flushes, rounded up
-
-template <int K, int DIR, int MODE, bool FD>
-__device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, const JobD& J, const SweepJob& SJ, unsigned long long* ring) {
-    const int lane = threadIdx.x;
-    const int C = uni(J.C), T = uni(SJ.T), n0 = uni(J.n0);
-    typedef const __attribute__((address_space(4))) int* kcip;   // constant address space + uniform index = scalar load
-    kcip QLO = (kcip)uni_ptr(sw.qlo + SJ.q_off);
-    kcip QHI = (kcip)uni_ptr(sw.qhi + SJ.q_off);
-    gcip band = (gcip)uni_ptr((const int*)(sw.band + SJ.band_off));
-    gcip st = (gcip)uni_ptr(J.st);
-    const PS_GLOBAL char* model = (const PS_GLOBAL char*)uni_ptr((const char*)J.model8);
-    const PS_GLOBAL v4d* levs = (const PS_GLOBAL v4d*)uni_ptr(J.lev[DIR]);
-    PS_GLOBAL unsigned char* codes = (PS_GLOBAL unsigned char*)uni_ptr(sw.codes + SJ.codes_off);
-    PS_GLOBAL char* rec = (PS_GLOBAL char*)uni_ptr((char*)(b.rec + J.mat_off[DIR]));
-    double* gcmax = uni_ptr(b.cmax + J.col_off[DIR]);
-    StripBest* SB = sw.sb + SJ.sb_off;
-    const double lsk = J.lsk, lst = J.lst, lex = J.lex, lin = J.lin, off = J.lik_offset, log2pi = b.log2pi;
-    const double NINF = -__builtin_inf();
-
-    // ---- what a lane fetches ahead of the step it is needed on
-    struct Ahead { v4i bd; int sp, sc, kc; };   // bd = {p0, p1, i0, i1} of columns j - 1, j; sp / sc = 5-mer of column j - 1 / j; kc: kept-column index (MODE 2)
-    gcip keep = (gcip)uni_ptr(J.keep[DIR]);
-    const int pitch = uni(J.pitch);
-    auto fetch = [&](int tt, int ql) -> Ahead {
-        const int q = ql + ((lane - ql) & 63);
-        const int j = clampi(tt - q, 1, max(C, 1));   // (a sequence without a 5-mer has no live step; its prefetches still need an address)
-        Ahead a;
-        a.bd = *(const PS_GLOBAL v4i_a4*)(band + 2 * (j - 1));
-        typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));
-        if (DIR == 0) {
-            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (j - 2));   // (ints of -1 around the list: column 0 reads as invalid)
-            a.sp = s2.x; a.sc = s2.y;
-        } else {                                                          // backward column j holds states[C - j]
-            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (C - j));
-            a.sc = s2.x; a.sp = s2.y;
-        }
-        a.kc = MODE == 2 ? keep[j] : -1;
-        return a;
-    };
-    auto model_row = [&](int state, double (&m)[8]) {
-        const PS_GLOBAL v2d* row = (const PS_GLOBAL v2d*)(model + (size_t)(unsigned)max(state, 0) * MODEL_ROW_BYTES);
-        const v2d q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
-        m[0] = q0.x; m[1] = q0.y; m[2] = q1.x; m[3] = q1.y; m[4] = q2.x; m[5] = q2.y; m[6] = q3.x; m[7] = q3.y;
-    };
-
-    // ---- lane state
-    double lev[K][4];        // level records of the lane's strip: {mean, stdv, 3 log stdv, 1 / stdv}
-    double pm[K];            // main scores of the previous column on the strip's rows; -infinity: no cell there
-    double pe[DIR ? K : 1];  // backward: main + emission of the previous column
-#pragma unroll
-    for (int r = 0; r < K; r++) { pm[r] = NINF; if (DIR) pe[r] = NINF; lev[r][0] = 0.0; lev[r][1] = 1.0; lev[r][2] = 0.0; lev[r][3] = 1.0; }
-    int qcur = -1;
-    double bot_m = NINF, bot_s = NINF, bot_e = NINF;   // the lane's last cell of the step: what the lane one down reads as its upper neighbour
-    double dm = NINF, de = NINF;                       // upper neighbour's main (backward: and main + emission) of the previous column
-    double lbest = 0.0;                  // strictly greater wins: the first cell of the strip (column, then row) holding its maximum
-    int lbt = 0, lbr = 0;
-    int flushed = 1, next_flush = 64;    // (MODE > 0) columns below `flushed` have their maximum in memory
-    if (MODE) {
-        for (int k = lane; k < RING; k += 64) ring[k] = 0ull;
-    }
-
-    int ql0 = QLO[1], ql1 = QLO[2];          // qlo of step t, t + 1 (scalar registers; T + Q_PAD entries, -1 behind T)
-    Ahead a0 = fetch(1, ql0), a1 = fetch(2, ql1);
-    double mr[8];
-    model_row(a0.sc, mr);
-
-    for (int t = 1; t < T; t++) {
-        const int ql2 = QLO[t + 2];
-        const Ahead a2 = fetch(t + 2, ql2);
-        const int ql = ql0;
-        const bool live = ql >= 0;                                   // (uniform) some strip is in band on this step
-        const int q = ql + ((lane - ql) & 63);
-        const int j = t - q;
-        if (live && q != qcur) {
-            // the lane takes its next strip: hand in the old one's maximum, fetch the new level records
-            if (DIR == 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
-            lbest = 0.0;
-            qcur = q;
-#pragma unroll
-            for (int r = 0; r < K; r++) {
-                const v4d v = levs[min(q * K + r, n0 - 1)];
-                lev[r][0] = v.x; lev[r][1] = v.y; lev[r][2] = v.z; lev[r][3] = v.w;
-                pm[r] = NINF;
-                if (DIR) pe[r] = NINF;
-            }
-        }
-        // emissions of the lane's K cells first: the model row is then free to receive the next column's (one step of lead)
-        double ov[K];
-#pragma unroll
-        for (int r = 0; r < K; r++) {
-            ov[r] = emission8<FD>(mr, lev[r], log2pi, off);
-            if (r & 1) __builtin_amdgcn_sched_barrier(0);            // two emissions in flight: enough to fill the pipe, few enough to stay in registers
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        model_row(a1.sc, mr);
-        if (live) {
-            const int base = q * K + 1;
-            const bool valid = j >= 1 && j <= C && a0.sc >= 0;     // (a column whose 5-mer is invalid is all zero: no cell takes part, cpp/Alignment.cpp:162-163)
-            const int ra = valid ? a0.bd.z - base : K, rb = valid ? a0.bd.w - base : -1;   // band rows relative to the strip
-            const int rc = a0.bd.x - base, rd_ = a0.bd.y - base;                          // previous column's band
-            const bool pzero = a0.sp < 0;                            // previous column invalid (or column 0): its scores read as zero
-            double um = wave_ror1(bot_m), us = wave_ror1(bot_s), ue = DIR ? wave_ror1(bot_e) : 0.0;
-            double dprev = dm, deprev = de;
-            dm = um; de = ue;
-            const double lbefore = lbest;
-            unsigned cw[(K + 3) / 4];                                // (forward) the step's codes, four to a register
-            double crun = 0.0;                                       // (MODE > 0) the lane's share of its column's maximum
-            PS_GLOBAL char* recp = rec + ((size_t)t * K * 64 + lane) * 16;
-            const bool kept = MODE == 2 && a0.kc >= 0 && j >= 1 && j <= C;
-            if (MODE == 2) {
-                // records of the lane's column: row i of the band [i0, i1] at REC[kc][i - i0]; recp = the strip's first row
-                recp = rec + ((int64_t)a0.kc * pitch + (base - a0.bd.z)) * 16;
-                if (kept && !valid)   // a kept column without a 5-mer: its band reads as zeros (cpp/Alignment.cpp:162-163)
-                    for (int r = max(0, a0.bd.z - base); r <= min(K - 1, a0.bd.w - base); r++) *(PS_GLOBAL v2d*)(recp + (size_t)r * 16) = (v2d){0.0, 0.0};
-            }
-#pragma unroll
-            for (int r = 0; r < K; r++) {
-                const double o = ov[r];
-                const bool act = r >= ra && r <= rb;
-                const bool top = r == ra;
-                const bool vd = r > rc && r <= rd_;                  // cpp/Alignment.cpp:207: p0 < i <= p1
-                const bool rd = vd && !pzero;
-                const double pmr = pm[r];
-                double L;
-                asm("v_max_f64 %0, %1, 0" : "=v"(L) : "v"(pmr));
-                const double D = rd ? dprev : 0.0;
-                const double cSTAY = DIR == 0 ? um + o + lst : ue + lst;      // backward: (main + emission) of the cell above
-                const double cEXT = DIR == 0 ? us + o + lex : us + lex;       // backward: `us` carries stay + emission
-                const double cINS = um + lin;
-                const double cSKIP = L + lsk;
-                const double cMATCH = DIR == 0 ? D + o : (rd ? deprev : 0.0);
-                const double cIGN = D + lin;
-                // the stay floor of a band's first row is -1e300 (cpp/Alignment.cpp:230): a value that only ever loses.  Where the record of
-                // the cell is kept for a bit-exact comparison (MODE 1) it is -BIG itself; elsewhere -1e300 with a zero low word does
-                // the same at one select (the high word) instead of two
-                const double floor_s = MODE == 1 ? (top ? -BIG : 0.0) : __hiloint2double(top ? __double2hiint(-BIG) : 0, 0);
-                const double t1 = fmax(floor_s, cSTAY);
-                const double ns = fmax(t1, cEXT);
-                double nm = fmax(0.0, cSKIP);
-                nm = fmax(nm, cMATCH);
-                nm = fmax(nm, cINS);
-                nm = fmax(nm, cIGN);
-                nm = fmax(nm, ns);
-                unsigned ss = 0u, sm = 4u;
-                if (DIR == 0) {
-                    // step codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order (first candidate equal to the maximum)
-                    ss = cSTAY > floor_s ? 1u : 0u;
-                    ss = cEXT > t1 ? 2u : ss;
-                    sm = cIGN == nm ? 3u : sm;
-                    sm = cINS == nm ? 2u : sm;
-                    sm = cMATCH == nm ? (vd ? 1u : 7u) : sm;
-                    sm = cSKIP == nm ? 0u : sm;
-                    sm = nm > 0.0 ? sm : 0u;
-                }
-                const double nmx = keep_or_absent(nm, act), nsx = keep_or_absent(ns, act);
-                if (DIR == 0) {
-                    // (a row outside the band carries both "score <= 0" bits — the walker stops there before it reads the step — because
-                    //  its scores are the absent-cell value; its step bits are whatever the selects left)
-                    unsigned w = sm | (ss << 3) | (nmx > 0.0 ? 0u : 32u) | (nsx > 0.0 ? 0u : 64u);   // (every constant an inline operand)
-                    asm volatile("" : "+v"(w));                      // keep the byte's shift out of the selects' constants (a VGPR per shifted literal otherwise)
-                    if ((r & 3) == 0) cw[r >> 2] = w; else cw[r >> 2] |= w << (8 * (r & 3));
-                }
-                dprev = pmr;
-                pm[r] = nmx;
-                if (DIR) { deprev = pe[r]; pe[r] = nmx + o; }
-                um = nmx;
-                us = DIR == 0 ? nsx : nsx + o;
-                if (DIR) ue = nmx + o;
-                if (MODE == 1) {
-                    double rx;   // the stored record: the cell; zeros where there is none (the stay value of a top row is -1e300 and stays so)
-                    asm("v_max_f64 %0, %1, 0" : "=v"(rx) : "v"(nmx));
-                    *(PS_GLOBAL v2d*)(recp + (size_t)r * 1024) = (v2d){rx, act ? ns : 0.0};
-                    crun = fmax(crun, rx);
-                }
-                if (MODE == 2) {
-                    if (act && kept) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){nm, ns};   // (a cell in band: nm >= 0)
-                    crun = fmax(crun, nmx);
-                }
-                if (DIR == 0) {
-                    const bool gt = nmx > lbest;
-                    asm("v_max_f64 %0, %1, %2" : "=v"(lbest) : "v"(lbest), "v"(nmx));   // (= gt ? nmx : lbest: one v_max instead of two selects; no canonicalisation of the operands)
-                    lbr = gt ? r : lbr;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            bot_m = um; bot_s = us; bot_e = ue;
-            if (DIR == 0) lbt = lbest > lbefore ? t : lbt;
-            if (MODE) atomicMax(&ring[(unsigned)j & (RING - 1)], (unsigned long long)__double_as_longlong(crun));   // (scores >= 0 order like their bit patterns; 0 is a no-op)
-            if (DIR == 0) {
-                // ---- the step's codes: per row group one coalesced store
-                PS_GLOBAL unsigned char* dst = codes + (size_t)t * (64 * K);
-                int r0 = 0;
-#pragma unroll
-                for (int g = 0; g < 8; g++) {
-                    const int sz = plane_sz(K - r0);
-                    PS_GLOBAL unsigned char* p = dst + 64 * r0 + lane * sz;
-                    if (sz == 16) {
-                        v4i v;
-                        v.x = cw[r0 / 4]; v.y = cw[r0 / 4 + 1]; v.z = cw[r0 / 4 + 2]; v.w = cw[r0 / 4 + 3];
-                        *(PS_GLOBAL v4i*)p = v;
-                    } else if (sz == 8) {
-                        typedef int v2i __attribute__((ext_vector_type(2)));
-                        v2i v;
-                        v.x = cw[r0 / 4]; v.y = cw[r0 / 4 + 1];
-                        *(PS_GLOBAL v2i*)p = v;
-                    } else if (sz == 4) {
-                        *(PS_GLOBAL unsigned*)p = cw[r0 / 4];
-                    } else if (sz == 2) {
-                        *(PS_GLOBAL unsigned short*)p = (unsigned short)(cw[r0 / 4] >> (8 * (r0 & 3)));
-                    } else {
-                        *p = (unsigned char)(cw[r0 / 4] >> (8 * (r0 & 3)));
-                    }
-                    r0 += sz;
-                    if (r0 >= K) break;
-                }
-            }
-            if (MODE && t >= next_flush) {
-                // the maxima of completed columns: everything left of the column the highest strip in band is working on
-                const int jdone = min(t - QHI[t], C + 1);
-                for (int col = flushed + lane; col < jdone; col += 64) {
-                    unsigned long long* e = &ring[(unsigned)col & (RING - 1)];
-                    const unsigned long long v = *e;
-                    *e = 0ull;
-                    gcmax[col] = __longlong_as_double((long long)v);
-                }
-                flushed = max(flushed, jdone);
-                next_flush = t + 64;
-            }
-        } else {
-            bot_m = NINF; bot_s = NINF; bot_e = NINF;
-        }
-        a0 = a1; a1 = a2;
-        ql0 = ql1; ql1 = ql2;
-    }
-    if (DIR == 0 && qcur >= 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
-    if (MODE)
-        for (int col = flushed + lane; col <= C; col += 64) gcmax[col] = __longlong_as_double((long long)ring[(unsigned)col & (RING - 1)]);
-}
+// registers: two waves per SIMD up to K = 10 on one wave (the level records of ten rows are 80 registers), one beyond
+#define PS_SWEEP_WPE(K) K <= 10 ? 2 : 1
 
 // forward-only batches: one wave per job
 template <int K, bool FD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 2 : 1, K <= 10 ? 2 : 1)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PS_SWEEP_WPE(K), PS_SWEEP_WPE(K))))
 void k_sweep(BatchD b, SweepD sw) {
     const JobD& J = b.jobs[blockIdx.x];
     if (J.out->inert) return;
-    sweep_body<K, 0, 0, FD>(b, sw, J, sw.sj[blockIdx.x], nullptr);
+    sweep_body<K, 1, 0, 0, FD>(b, sw, J, sw.sj[blockIdx.x], nullptr, nullptr);
 }
 
 // Alignment::update batches: one wave per (job, direction), sweep job jd = 2 * job + direction
 template <int K, bool FD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 2 : 1, K <= 10 ? 2 : 1)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PS_SWEEP_WPE(K), PS_SWEEP_WPE(K))))
 void k_sweep2(BatchD b, SweepD sw) {
-    __shared__ unsigned long long ring[RING];
+    __shared__ unsigned long long ring[ring_cols(1)];
     const int jd = blockIdx.x;
     const JobD& J = b.jobs[jd >> 1];
     if (J.out->inert) return;
-    if ((jd & 1) == 0) sweep_body<K, 0, 1, FD>(b, sw, J, sw.sj[jd], ring);
-    else sweep_body<K, 1, 1, FD>(b, sw, J, sw.sj[jd], ring);
+    if ((jd & 1) == 0) sweep_body<K, 1, 0, 1, FD>(b, sw, J, sw.sj[jd], ring, nullptr);
+    else sweep_body<K, 1, 1, 1, FD>(b, sw, J, sw.sj[jd], ring, nullptr);
 }
 
 // Alignment::update batches whose edit list reads few columns: the same sweeps with column-sparse records
 template <int K, bool FD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 2 : 1, K <= 10 ? 2 : 1)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PS_SWEEP_WPE(K), PS_SWEEP_WPE(K))))
 void k_sweeps(BatchD b, SweepD sw) {
-    __shared__ unsigned long long ring[RING];
+    __shared__ unsigned long long ring[ring_cols(1)];
     const int jd = blockIdx.x;
     const JobD& J = b.jobs[jd >> 1];
     if (J.out->inert) return;
-    if ((jd & 1) == 0) sweep_body<K, 0, 2, FD>(b, sw, J, sw.sj[jd], ring);
-    else sweep_body<K, 1, 2, FD>(b, sw, J, sw.sj[jd], ring);
+    if ((jd & 1) == 0) sweep_body<K, 1, 0, 2, FD>(b, sw, J, sw.sj[jd], ring, nullptr);
+    else sweep_body<K, 1, 1, 2, FD>(b, sw, J, sw.sj[jd], ring, nullptr);
 }
 
 // the global maximum and its first cell — smallest column, then smallest row (cpp/Alignment.cpp:158, 270: strict '>' over columns
@@ -426,13 +143,14 @@ __global__ __launch_bounds__(64) void k_best(BatchD b, SweepD sw) {
 template <int K>
 struct StripCodes {
     const unsigned char* codes;
+    int nl;                                 // lanes of a sweep (64 per wave): strip q sits on lane q mod nl
     static constexpr bool ROWFAST = true;   // consecutive threads take consecutive rows: K contiguous bytes per strip
     __device__ __forceinline__ void prep(int) {}
     __device__ __forceinline__ unsigned short word(int ti, int tj, int a, int c) const {
         const int r = ti - a, col = tj - c;
         if (r < 1 || col < 1) return (unsigned short)0xC000u;   // outside the matrix: score 0, the walk stops
         const int q = (r - 1) / K, rr = (r - 1) - q * K;
-        const unsigned by = codes[(size_t)(col + q) * (64 * K) + code_off<K>(q & 63, rr)];
+        const unsigned by = codes[(size_t)(col + q) * (nl * K) + code_off<K>(q & (nl - 1), rr, nl)];
         const unsigned sm = by & 7u, ss = (by >> 3) & 3u;
         return (unsigned short)((sm == 7u ? (unsigned)M_IMPL : sm) | ((ss ? 3u + ss : 0u) << 8) | ((by & 0x60u) << 9));
     }
@@ -443,6 +161,7 @@ __global__ __launch_bounds__(256) void k_backtrace_s(BatchD b, SweepD sw) {
     const JobD& J = b.jobs[blockIdx.x];
     StripCodes<K> src;
     src.codes = sw.codes + sw.sj[blockIdx.x * sw.ndir].codes_off;
+    src.nl = sw.nl;
     bt_walk(J, src);
 }
 
@@ -571,13 +290,42 @@ int likes_max_states() { return LK_MAXC - 4; }
 // =================================================================================================
 #define PS_LAUNCH_CHECK() PS_HIP(hipGetLastError())
 
-static const int K_LIST[] = {4, 6, 10, 16, 24, 32};
-// smallest strip height whose window probably fits: band rows per step ~ (2W + 1) / (K + levels per base) + 2
-int sweep_guess_k(int W) {
-    for (int K : K_LIST) if ((2 * W + 1) / (K + 1) + 3 <= WIN_MAX) return K;
-    return 0;
+// Forms of the strip sweep: K rows per lane on NW wavefronts per sweep (NL = 64 NW lanes).  The strips in band on one step form a
+// window of about (2W + 1) / (K + levels per base) + 2 strips, which must fit NL - 2 lanes.
+//   NW = 1   one wavefront per sweep: the fewest instructions per cell at K = 10 for the default width (57 of 64 lanes busy), ~27 ms
+//            for a 10 kb sweep whatever the chip could do
+//   NW = 2   K = 4: the same SIMD time per sweep (120 of 128 lanes busy; the per-step overhead of a lane is spread over 4 cells
+//            instead of 10) in half the time, 80 registers fewer (the level records of six rows)
+//   NW = 4   K = 2: a quarter more SIMD time, a third of the time: launches that leave most of the chip idle
+static const int K_LIST1[] = {4, 6, 10, 16, 24, 32, 0};
+static const int K_LIST2[] = {4, 5, 6, 10, 0};
+static const int K_LIST4[] = {2, 3, 4, 6, 0};
+static const int* k_list(int NW) { return NW == 1 ? K_LIST1 : NW == 2 ? K_LIST2 : NW == 4 ? K_LIST4 : nullptr; }
+int sweep_win_max(int NW) { return 64 * NW - 2; }
+static int guess_window(int W, int K) { return (2 * W + 1) / (K + 1) + 3; }
+
+// smallest strip height on NW wavefronts whose window probably fits (K = 0: none)
+SweepForm sweep_guess_form(int W, int NW) {
+    SweepForm f;
+    const int* l = k_list(NW);
+    if (!l) return f;
+    for (; *l; l++) if (guess_window(W, *l) <= sweep_win_max(NW)) { f.K = *l; f.NW = NW; return f; }
+    return f;
 }
-static int next_k(int K) { for (int k : K_LIST) if (k > K) return k; return 0; }
+// the next larger form after a window that did not fit: the next strip height on the same number of wavefronts, else the
+// single-wavefront form of that capacity
+SweepForm sweep_next_form(SweepForm f, int win) {
+    SweepForm n;
+    for (const int* l = k_list(f.NW); l && *l; l++) if (*l > f.K) { n.K = *l; n.NW = f.NW; return n; }
+    if (f.NW > 1)
+        for (const int* l = K_LIST1; *l; l++) if (*l * sweep_win_max(1) > f.K * win) { n.K = *l; n.NW = 1; return n; }
+    return n;
+}
+bool sweep_form_exists(int K, int NW) {
+    for (const int* l = k_list(NW); l && *l; l++) if (*l == K) return true;
+    return false;
+}
+int sweep_guess_k(int W) { return sweep_guess_form(W, 1).K; }
 
 template <int K>
 static void sweep_launch_k(Runtime* rt, const BatchD& b, const SweepD& sw) {
@@ -599,17 +347,18 @@ static void bt_launch_k(Runtime* rt, const BatchD& b, const SweepD& sw) {
     hipLaunchKernelGGL((k_backtrace_s<K>), dim3(b.njobs), dim3(256), 0, rt->stream, b, sw);
 }
 
-// bytes one job takes at strip height K: step codes (forward), and with full = true the records of both directions
-double sweep_job_bytes(int n0, int C, int K, bool full) {
+// bytes one job takes in form f: step codes (forward), and with full = true the records of both directions
+double sweep_job_bytes(int n0, int C, SweepForm f, bool full) {
+    const int K = std::max(f.K, 1);
     const double steps = (double)C + (n0 + K - 1) / K + 1;
-    return steps * 64.0 * K * (full ? 1.0 + 2 * 16.0 : 1.0);
+    return steps * 64.0 * f.NW * K * (full ? 1.0 + 2 * 16.0 : 1.0);
 }
 
-// the strip tables of a batch at strip height K: sweep-job records (one per job and direction), band table, qlo / qhi + the
-// widest window (read back by the caller).  bt.ndir == 2: also the record offsets of both directions (JobD.mat_off, JobD.K).
-int sweep_prepare(Runtime* rt, Batch& bt, int K) {
+// the strip tables of a batch in form f: sweep-job records (one per job and direction), band table, qlo / qhi + the
+// widest window (read back by the caller).  bt.ndir == 2: also the record offsets of both directions (JobD.mat_off, JobD.K, JobD.NL).
+int sweep_prepare(Runtime* rt, Batch& bt, SweepForm f) {
     const BatchD& b = bt.d;
-    const int nd = bt.ndir;
+    const int nd = bt.ndir, K = f.K, NL = 64 * f.NW;
     std::vector<SweepJob>& sj = bt.sjobs;
     sj.resize(bt.jobs.size() * nd);
     int64_t band_tot = 0, q_tot = 0, sb_tot = 0, code_tot = 0, rec_tot = 0;
@@ -617,6 +366,7 @@ int sweep_prepare(Runtime* rt, Batch& bt, int K) {
     for (size_t k = 0; k < bt.jobs.size(); k++) {
         JobD& j = bt.jobs[k];
         j.K = nd == 2 ? (bt.sparse ? -1 : K) : 0;
+        j.NL = NL;
         if (bt.sparse) j.pitch = (std::min(2 * j.W + 1, j.n0) + 3) & ~1;   // rows of the widest band (+ slack), even: 32-byte aligned columns
         for (int d = 0; d < nd; d++) {
             SweepJob s;
@@ -625,14 +375,14 @@ int sweep_prepare(Runtime* rt, Batch& bt, int K) {
             s.band_off = band_tot; band_tot += j.C + 2;
             s.q_off = q_tot; q_tot += s.T + Q_PAD;
             s.sb_off = sb_tot; if (d == 0) sb_tot += std::max(s.Q, 1);
-            s.codes_off = code_tot; if (d == 0) code_tot += (int64_t)s.T * 64 * K;
+            s.codes_off = code_tot; if (d == 0) code_tot += (int64_t)s.T * NL * K;
             if (nd == 2 && bt.sparse) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)bt.nkeep[2 * k + d] * j.pitch; }
-            else if (nd == 2) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)s.T * 64 * K; }
+            else if (nd == 2) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)s.T * NL * K; }
             maxT = std::max(maxT, s.T);
             sj[k * nd + d] = s;
         }
     }
-    bt.sweep_K = K; bt.sweep_maxT = maxT; bt.sweep_code_bytes = code_tot; bt.sweep_sb = sb_tot; bt.sweep_recs = rec_tot;
+    bt.sweep_K = K; bt.sweep_NW = f.NW; bt.sweep_maxT = maxT; bt.sweep_code_bytes = code_tot; bt.sweep_sb = sb_tot; bt.sweep_recs = rec_tot;
     PS_TRY(rt->buf("sw_jobs").ensure(std::max<size_t>(sj.size(), 1) * sizeof(SweepJob)));
     PS_TRY(rt->buf("sw_band").ensure(std::max<int64_t>(band_tot, 1) * sizeof(int2)));
     PS_TRY(rt->buf("sw_qlo").ensure(std::max<int64_t>(q_tot, 1) * sizeof(int)));
@@ -649,6 +399,7 @@ int sweep_prepare(Runtime* rt, Batch& bt, int K) {
     sw.maxwin = rt->buf("sw_win").as<int>();
     sw.codes = nullptr;
     sw.K = K;
+    sw.nl = NL;
     sw.ndir = nd;
     sw.sparse = nd == 2 && bt.sparse ? 1 : 0;
     PS_HIP(hipMemsetAsync(sw.maxwin, 0, sizeof(int), rt->stream));
@@ -662,24 +413,32 @@ int sweep_prepare(Runtime* rt, Batch& bt, int K) {
 int sweep_run(Runtime* rt, Batch& bt) {
     const BatchD& b = bt.d;
     SweepD& sw = bt.sd;
-    const int K = bt.sweep_K;
+    const int K = bt.sweep_K, NW = bt.sweep_NW;
     PS_HIP(hipMemsetAsync(sw.sb, 0, (size_t)std::max<int64_t>(bt.sweep_sb, 1) * sizeof(StripBest), rt->stream));
     prof_begin(rt);
-    switch (K) {
-        case 4: sweep_launch_k<4>(rt, b, sw); break;
-        case 6: sweep_launch_k<6>(rt, b, sw); break;
-        case 10: sweep_launch_k<10>(rt, b, sw); break;
-        case 16: sweep_launch_k<16>(rt, b, sw); break;
-        case 24: sweep_launch_k<24>(rt, b, sw); break;
-        case 32: sweep_launch_k<32>(rt, b, sw); break;
-        default: return fail(PS_ERR_BAD_ARG, "sweep_run: strip height");
+    if (NW > 1) {
+        if (!b.fastdiv || !sweepw_launch(rt, b, sw, K, NW)) return fail(PS_ERR_BAD_ARG, "sweep_run: no such multi-wavefront form");
+    } else {
+        switch (K) {
+            case 4: sweep_launch_k<4>(rt, b, sw); break;
+            case 6: sweep_launch_k<6>(rt, b, sw); break;
+            case 10: sweep_launch_k<10>(rt, b, sw); break;
+            case 16: sweep_launch_k<16>(rt, b, sw); break;
+            case 24: sweep_launch_k<24>(rt, b, sw); break;
+            case 32: sweep_launch_k<32>(rt, b, sw); break;
+            default: return fail(PS_ERR_BAD_ARG, "sweep_run: strip height");
+        }
     }
     PS_LAUNCH_CHECK();
     prof_end(rt, "sweep", 0.0);
+    if (rt->prof_on && NW > 1) rt->prof[NW == 2 ? "sweep_w2" : "sweep_w4"].launches++;   // (which form ran: a host-side count, no event pair)
     hipLaunchKernelGGL(k_best, dim3(b.njobs), dim3(64), 0, rt->stream, b, sw);
     if (bt.ndir == 2) PS_TRY(launch_prefix(rt, b, 2));   // running MaxInfo per column of both directions (the strip jobs' best cell is k_best's)
     switch (K) {
+        case 2: bt_launch_k<2>(rt, b, sw); break;
+        case 3: bt_launch_k<3>(rt, b, sw); break;
         case 4: bt_launch_k<4>(rt, b, sw); break;
+        case 5: bt_launch_k<5>(rt, b, sw); break;
         case 6: bt_launch_k<6>(rt, b, sw); break;
         case 10: bt_launch_k<10>(rt, b, sw); break;
         case 16: bt_launch_k<16>(rt, b, sw); break;
@@ -699,8 +458,5 @@ int sweep_run(Runtime* rt, Batch& bt) {
     }
     return PS_OK;
 }
-
-int sweep_next_k(int K) { return next_k(K); }
-int sweep_win_max() { return WIN_MAX; }
 
 }  // namespace ps

@@ -1,0 +1,392 @@
+// ps_sweep_body.h — the strip sweep's device body, shared by ps_sweep.hip (one wavefront per sweep) and ps_sweepw.hip (two or
+// four wavefronts per sweep).  See ps_sweep.hip for the geometry and the reference citations.
+#ifndef PS_SWEEP_BODY_H_
+#define PS_SWEEP_BODY_H_
+
+#include "ps_dev.h"
+#include "ps_host.h"
+
+namespace ps {
+
+// ---- byte layout of one step's codes: row groups ("planes") of 16 / 8 / 4 / 2 / 1 rows, each [NL lanes][rows of the group] ----
+__host__ __device__ constexpr int plane_sz(int rem) { return rem >= 16 ? 16 : rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1; }
+template <int K>
+__device__ __forceinline__ int code_off(int lane, int r, int nl) {
+    int r0 = 0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        const int sz = plane_sz(K - r0);
+        if (r < r0 + sz) return nl * r0 + lane * sz + (r - r0);
+        r0 += sz;
+        if (r0 >= K) break;
+    }
+    return 0;
+}
+
+struct StripBest { double v; int i, j; };
+constexpr int Q_PAD = 8;          // qlo entries behind T (all -1): the sweep looks three steps ahead
+// strips in band on one step: at most NL - 2, two lanes stay idle (a lane is never handed its next strip in the step it leaves one)
+
+__device__ __forceinline__ double wave_ror1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C /*wave_ror:1*/, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// `x` where keep, else a huge negative FINITE number: only the high word is selected (0xFFEFFFFF: -1.797e308 whatever the low word
+// holds).  It stands for "no cell here" exactly as -infinity does — it loses every maximum against a real score (>= 0), against the
+// floors 0 and -1e300 and in every `>` test, adding an emission or a transition term leaves it where it is, and two of them are never
+// added — at one v_cndmask instead of two.
+__device__ __forceinline__ double keep_or_absent(double x, bool keep) {
+    const int hi = keep ? __double2hiint(x) : (int)0xFFEFFFFF;
+    return __hiloint2double(hi, __double2loint(x));
+}
+
+// columns of the LDS ring of per-column maxima: the widest window (NL - 2 strips) + the 64 steps between two flushes, rounded up
+__host__ __device__ constexpr int ring_cols(int nw) { return nw <= 2 ? 256 : 512; }
+constexpr int HAND_DOUBLES = 4;   // LDS hand-off record of a wave's last lane: {main, stay (+ emission), main + emission, -}
+
+// One sweep on NW wavefronts (one workgroup of NL = 64 NW lanes; strip q sits on lane q mod NL).  DIR 0 / 1: forward / backward fill
+// (cpp/Alignment.cpp:111-274 / 280-444: the backward cell adds its emission when it is LEFT, so what a lane hands down and keeps
+// for the diagonal is {main, stay + emission, main + emission}).  MODE 0 (ScoreAlignments): only the forward step codes and the
+// per-strip maxima leave the chip.  MODE 1 / 2: the sweep of an Alignment::update (ScoreMutations) — also the per-column maxima
+// (MaxInfo, cpp/Alignment.cpp:158, 270) through an LDS ring to cmax, and {main, stay} records: of every cell,
+// REC[step][row of the strip][lane] (MODE 1: one coalesced store per row and step), or only of the columns the edit list will read
+// (MODE 2: scoreMutation / columnMax, cpp/Alignment.cpp:447-512, cpp/Alignment.h:181-214, read the forward columns max(start-4, 0)
+// and max(start-3, 1) and two backward columns per edit): the lane whose column is kept (JobD.keep, fetched with the band record)
+// writes its in-band cells to REC[kept column][row - i0].
+//
+// NW > 1: the cell above the first row of lane 0 of a wave is the last cell of lane 63 of the wave before it (cyclically).  Every
+// wave's lane 63 leaves its {main, stay, main + emission} in LDS at the end of a step (`hand`, two slots alternating by step), the
+// waves meet at one LDS-only barrier per step, and lane 0 picks the record up at the top of the next step — the read's latency is
+// covered by the step's emissions, which do not depend on it.  Nothing else crosses waves: the ring of column maxima is shared
+// (LDS atomics), every other table is per lane.
+template <int K, int NW, int DIR, int MODE, bool FD>
+__device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, const JobD& J, const SweepJob& SJ, unsigned long long* ring, double* hand) {
+    constexpr int NL = 64 * NW;
+    constexpr int RING = ring_cols(NW);
+    const int lane = threadIdx.x;                                  // lane of the sweep, 0 .. NL - 1
+    const int wv = NW > 1 ? uni((int)threadIdx.x >> 6) : 0;       // its wave
+    const int C = uni(J.C), T = uni(SJ.T), n0 = uni(J.n0);
+    typedef const __attribute__((address_space(4))) int* kcip;   // constant address space + uniform index = scalar load
+    kcip QLO = (kcip)uni_ptr(sw.qlo + SJ.q_off);
+    kcip QHI = (kcip)uni_ptr(sw.qhi + SJ.q_off);
+    gcip band = (gcip)uni_ptr((const int*)(sw.band + SJ.band_off));
+    gcip st = (gcip)uni_ptr(J.st);
+    const PS_GLOBAL char* model = (const PS_GLOBAL char*)uni_ptr((const char*)J.model8);
+    const PS_GLOBAL v4d* levs = (const PS_GLOBAL v4d*)uni_ptr(J.lev[DIR]);
+    PS_GLOBAL unsigned char* codes = (PS_GLOBAL unsigned char*)uni_ptr(sw.codes + SJ.codes_off);
+    PS_GLOBAL char* rec = (PS_GLOBAL char*)uni_ptr((char*)(b.rec + J.mat_off[DIR]));
+    PS_GLOBAL double* gcmax = (PS_GLOBAL double*)uni_ptr(b.cmax + J.col_off[DIR]);
+    StripBest* SB = sw.sb + SJ.sb_off;
+    const double lsk = J.lsk, lst = J.lst, lex = J.lex, lin = J.lin, off = J.lik_offset, log2pi = b.log2pi;
+    const double NINF = -__builtin_inf();
+
+    // ---- what a lane fetches ahead of the step it is needed on
+    struct Ahead { v4i bd; int sp, sc, kc; };   // bd = {p0, p1, i0, i1} of columns j - 1, j; sp / sc = 5-mer of column j - 1 / j; kc: kept-column index (MODE 2)
+    gcip keep = (gcip)uni_ptr(J.keep[DIR]);
+    const int pitch = uni(J.pitch);
+    auto fetch = [&](int tt, int ql) -> Ahead {
+        const int q = ql + ((lane - ql) & (NL - 1));
+        const int j = clampi(tt - q, 1, max(C, 1));   // (a sequence without a 5-mer has no live step; its prefetches still need an address)
+        Ahead a;
+        a.bd = *(const PS_GLOBAL v4i_a4*)(band + 2 * (j - 1));
+        typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));
+        if (DIR == 0) {
+            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (j - 2));   // (ints of -1 around the list: column 0 reads as invalid)
+            a.sp = s2.x; a.sc = s2.y;
+        } else {                                                          // backward column j holds states[C - j]
+            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (C - j));
+            a.sc = s2.x; a.sp = s2.y;
+        }
+        a.kc = MODE == 2 ? keep[j] : -1;
+        return a;
+    };
+    auto model_row = [&](int state, double (&m)[8]) {
+        const PS_GLOBAL v2d* row = (const PS_GLOBAL v2d*)(model + (size_t)(unsigned)max(state, 0) * MODEL_ROW_BYTES);
+        const v2d q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+        m[0] = q0.x; m[1] = q0.y; m[2] = q1.x; m[3] = q1.y; m[4] = q2.x; m[5] = q2.y; m[6] = q3.x; m[7] = q3.y;
+    };
+
+    // ---- lane state
+    double lev[K][4];        // level records of the lane's strip: {mean, stdv, 3 log stdv, 1 / stdv}
+    double pm[K];            // main scores of the previous column on the strip's rows; -infinity: no cell there
+    double pe[DIR ? K : 1];  // backward: main + emission of the previous column
+#pragma unroll
+    for (int r = 0; r < K; r++) { pm[r] = NINF; if (DIR) pe[r] = NINF; lev[r][0] = 0.0; lev[r][1] = 1.0; lev[r][2] = 0.0; lev[r][3] = 1.0; }
+    int qcur = -1;
+    double bot_m = NINF, bot_s = NINF, bot_e = NINF;   // the lane's last cell of the step: what the lane one down reads as its upper neighbour
+    double dm = NINF, de = NINF;                       // upper neighbour's main (backward: and main + emission) of the previous column
+    double lbest = 0.0;                  // strictly greater wins: the first cell of the strip (column, then row) holding its maximum
+    int lbt = 0, lbr = 0;
+    int flushed = 1, next_flush = 64;    // (MODE > 0) columns below `flushed` have their maximum in memory
+    if (MODE) {
+        for (int k = lane; k < RING; k += NL) ring[k] = 0ull;
+    }
+    const int pw = NW > 1 ? (wv + NW - 1) % NW : 0;                // the wave whose lane 63 is the upper neighbour of this wave's lane 0
+    const bool l0 = NW > 1 && (lane & 63) == 0, l63 = NW > 1 && (lane & 63) == 63;
+    if (NW > 1) {
+        if (l63) {
+#pragma unroll
+            for (int s = 0; s < 2; s++) { double* h = hand + (s * NW + wv) * HAND_DOUBLES; h[0] = NINF; h[1] = NINF; h[2] = NINF; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    int ql0 = QLO[1], ql1 = QLO[2], ql2 = QLO[3];   // qlo of step t, t + 1, t + 2 (scalar registers; T + Q_PAD entries, -1 behind T)
+    Ahead aA = fetch(1, ql0), aB = fetch(2, ql1), aC = aB;   // three pipeline stages whose roles rotate with the step (the loop is unrolled by three)
+    double mr[8];
+    model_row(aA.sc, mr);
+    // The level records of the strip a lane works on at step t + 1 are fetched during step t, behind the step's emissions (the last
+    // readers of the old ones): a strip's rows are read once per sweep, so the loads miss every cache, and issued at the top of
+    // the step they are first used on they stalled the wave — and behind the step's barrier the whole workgroup — for the whole miss.
+    int qlev = -1;                            // the strip whose level records are in `lev`
+    auto load_levels = [&](int ql_next) {
+        if (ql_next < 0) return;
+        const int qn = ql_next + ((lane - ql_next) & (NL - 1));
+        if (qn != qlev) {
+            qlev = qn;
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                const v4d v = levs[min(qn * K + r, n0 - 1)];
+                lev[r][0] = v.x; lev[r][1] = v.y; lev[r][2] = v.z; lev[r][3] = v.w;
+            }
+        }
+    };
+    load_levels(ql0);
+
+    // ---- stores of a step leave one step late, behind the next step's emissions.  A wave's vector-memory operations retire in
+    // issue order, so a wait for a load (the model row of the next column) is also a wait for every store issued before it: with
+    // the stores of a step issued in that step, every step ended in a drain of its own code bytes (~20 % of a lone wave's time).
+    // Held back until the next step's loads have been waited for, a step's stores have a whole step to complete in.
+    constexpr bool DEFER_REC = MODE == 2 && K <= 5;                 // (kept-column records: 4 K + 2 registers to hold them back)
+    bool pend = false;                                               // (uniform) the previous step was live: it has stores waiting
+    unsigned cwp[(K + 3) / 4];                                       // its codes, four to a register
+    double pnm[DEFER_REC ? K : 1], pns[DEFER_REC ? K : 1];           // its kept-column records
+    unsigned pmask = 0u;                                             // rows of them to store
+    int poff = 0;                                                    // byte offset of the strip's first row in the record pool
+#pragma unroll
+    for (int w = 0; w < (K + 3) / 4; w++) cwp[w] = 0u;
+    auto put_codes = [&](int tp, const unsigned (&cw)[(K + 3) / 4]) {   // the codes of step tp: per row group one coalesced store
+        PS_GLOBAL unsigned char* dst = codes + (size_t)tp * (NL * K);
+        int r0 = 0;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int sz = plane_sz(K - r0);
+            PS_GLOBAL unsigned char* p = dst + NL * r0 + lane * sz;
+            if (sz == 16) {
+                v4i v;
+                v.x = cw[r0 / 4]; v.y = cw[r0 / 4 + 1]; v.z = cw[r0 / 4 + 2]; v.w = cw[r0 / 4 + 3];
+                *(PS_GLOBAL v4i*)p = v;
+            } else if (sz == 8) {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                v2i v;
+                v.x = cw[r0 / 4]; v.y = cw[r0 / 4 + 1];
+                *(PS_GLOBAL v2i*)p = v;
+            } else if (sz == 4) {
+                *(PS_GLOBAL unsigned*)p = cw[r0 / 4];
+            } else if (sz == 2) {
+                *(PS_GLOBAL unsigned short*)p = (unsigned short)(cw[r0 / 4] >> (8 * (r0 & 3)));
+            } else {
+                *p = (unsigned char)(cw[r0 / 4] >> (8 * (r0 & 3)));
+            }
+            r0 += sz;
+            if (r0 >= K) break;
+        }
+    };
+    auto put_pending = [&](int tp) {
+        if (!pend) return;
+        if (DIR == 0) put_codes(tp, cwp);
+        if (DEFER_REC) {
+            if (pmask) {
+                PS_GLOBAL char* recp = rec + (int64_t)poff;
+#pragma unroll
+                for (int r = 0; r < K; r++)
+                    if ((pmask >> r) & 1u) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){pnm[r], pns[r]};
+            }
+        }
+    };
+
+    auto step = [&](const int t, const Ahead& a0, const Ahead& a1, Ahead& a2) __attribute__((always_inline)) {
+        const int ql = ql0;
+        const bool live = ql >= 0;                                   // (uniform over the workgroup) some strip is in band on this step
+        const int q = ql + ((lane - ql) & (NL - 1));
+        const int j = t - q;
+        if (live && q != qcur) {
+            // the lane takes its next strip (its level records are in place: load_levels of the step before): hand in the old one's maximum
+            if (DIR == 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
+            lbest = 0.0;
+            qcur = q;
+#pragma unroll
+            for (int r = 0; r < K; r++) { pm[r] = NINF; if (DIR) pe[r] = NINF; }
+        }
+        const int ql3 = QLO[t + 3];                                  // (one step further ahead than it is needed: the scalar load's latency stays off the step)
+        a2 = fetch(t + 2, ql2);
+        double hm = NINF, hs = NINF, he = NINF;                      // (NW > 1) what the previous wave's lane 63 left at the end of step t - 1
+        if (NW > 1) {
+            const double* h = hand + (((t - 1) & 1) * NW + pw) * HAND_DOUBLES;
+            const v2d hv = *(const v2d*)h;
+            hm = hv.x; hs = hv.y;
+            if (DIR) he = h[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);                           // (the step's loads are issued before its first emission waits for the model row)
+        // emissions of the lane's K cells first: the model row is then free to receive the next column's (one step of lead)
+        double ov[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            ov[r] = emission8<FD>(mr, lev[r], log2pi, off);
+            // (pinned here: left to itself the compiler sinks the emissions into the `live` block below, behind the next model row's
+            //  loads — which then need registers of their own, a copy at the end of the step and a full `s_waitcnt vmcnt(0)` for it)
+            asm volatile("" : "+v"(ov[r]));
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);            // two emissions in flight: enough to fill the pipe, few enough to stay in registers
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        put_pending(t - 1);
+        load_levels(ql1);
+        model_row(a1.sc, mr);
+        pend = live;
+        if (live) {
+            const int base = q * K + 1;
+            const bool valid = j >= 1 && j <= C && a0.sc >= 0;     // (a column whose 5-mer is invalid is all zero: no cell takes part, cpp/Alignment.cpp:162-163)
+            const int ra = valid ? a0.bd.z - base : K, rb = valid ? a0.bd.w - base : -1;   // band rows relative to the strip
+            const int rc = a0.bd.x - base, rd_ = a0.bd.y - base;                          // previous column's band
+            const bool pzero = a0.sp < 0;                            // previous column invalid (or column 0): its scores read as zero
+            double um = wave_ror1(bot_m), us = wave_ror1(bot_s), ue = DIR ? wave_ror1(bot_e) : 0.0;
+            if (NW > 1) { um = l0 ? hm : um; us = l0 ? hs : us; if (DIR) ue = l0 ? he : ue; }
+            double dprev = dm, deprev = de;
+            dm = um; de = ue;
+            const double lbefore = lbest;
+            double crun = 0.0;                                       // (MODE > 0) the lane's share of its column's maximum
+            PS_GLOBAL char* recp = rec + ((size_t)t * K * NL + lane) * 16;
+            const bool kept = MODE == 2 && a0.kc >= 0 && j >= 1 && j <= C;
+            if (MODE == 2) {
+                // records of the lane's column: row i of the band [i0, i1] at REC[kc][i - i0]; recp = the strip's first row
+                const int64_t ro = ((int64_t)a0.kc * pitch + (base - a0.bd.z)) * 16;
+                recp = rec + ro;
+                if (DEFER_REC) { poff = (int)ro; pmask = 0u; }      // (kept columns of one direction of one job: < 2^31 bytes, sweep_prepare)
+                if (kept && !valid)   // a kept column without a 5-mer: its band reads as zeros (cpp/Alignment.cpp:162-163)
+                    for (int r = max(0, a0.bd.z - base); r <= min(K - 1, a0.bd.w - base); r++) *(PS_GLOBAL v2d*)(recp + (size_t)r * 16) = (v2d){0.0, 0.0};
+            }
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                const double o = ov[r];
+                const bool act = r >= ra && r <= rb;
+                const bool top = r == ra;
+                const bool vd = r > rc && r <= rd_;                  // cpp/Alignment.cpp:207: p0 < i <= p1
+                const bool rd = vd && !pzero;
+                const double pmr = pm[r];
+                double L;
+                asm("v_max_f64 %0, %1, 0" : "=v"(L) : "v"(pmr));
+                const double D = rd ? dprev : 0.0;
+                const double cSTAY = DIR == 0 ? um + o + lst : ue + lst;      // backward: (main + emission) of the cell above
+                const double cEXT = DIR == 0 ? us + o + lex : us + lex;       // backward: `us` carries stay + emission
+                const double cINS = um + lin;
+                const double cSKIP = L + lsk;
+                const double cMATCH = DIR == 0 ? D + o : (rd ? deprev : 0.0);
+                const double cIGN = D + lin;
+                // the stay floor of a band's first row is -1e300 (cpp/Alignment.cpp:230): a value that only ever loses.  Where the record of
+                // the cell is kept for a bit-exact comparison (MODE 1) it is -BIG itself; elsewhere -1e300 with a zero low word does
+                // the same at one select (the high word) instead of two
+                const double floor_s = MODE == 1 ? (top ? -BIG : 0.0) : __hiloint2double(top ? __double2hiint(-BIG) : 0, 0);
+                const double t1 = fmax(floor_s, cSTAY);
+                const double ns = fmax(t1, cEXT);
+                double nm = fmax(0.0, cSKIP);
+                nm = fmax(nm, cMATCH);
+                nm = fmax(nm, cINS);
+                nm = fmax(nm, cIGN);
+                nm = fmax(nm, ns);
+                unsigned ss = 0u, sm = 4u;
+                if (DIR == 0) {
+                    // step codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order (first candidate equal to the maximum)
+                    const unsigned mcode = vd ? 1u : 7u;
+                    ss = cSTAY > floor_s ? 1u : 0u;
+                    ss = cEXT > t1 ? 2u : ss;
+                    sm = cIGN == nm ? 3u : sm;
+                    sm = cINS == nm ? 2u : sm;
+                    sm = cMATCH == nm ? mcode : sm;
+                    sm = cSKIP == nm ? 0u : sm;
+                    sm = nm > 0.0 ? sm : 0u;
+                }
+                const double nmx = keep_or_absent(nm, act), nsx = keep_or_absent(ns, act);
+                if (DIR == 0) {
+                    // (a row outside the band carries both "score <= 0" bits — the walker stops there before it reads the step — because
+                    //  its scores are the absent-cell value; its step bits are whatever the selects left)
+                    unsigned w = sm | (ss << 3) | (nmx > 0.0 ? 0u : 32u) | (nsx > 0.0 ? 0u : 64u);   // (every constant an inline operand)
+                    asm volatile("" : "+v"(w));                      // keep the byte's shift out of the selects' constants (a VGPR per shifted literal otherwise)
+                    if ((r & 3) == 0) cwp[r >> 2] = w; else cwp[r >> 2] |= w << (8 * (r & 3));
+                }
+                dprev = pmr;
+                pm[r] = nmx;
+                if (DIR) { deprev = pe[r]; pe[r] = nmx + o; }
+                um = nmx;
+                us = DIR == 0 ? nsx : nsx + o;
+                if (DIR) ue = nmx + o;
+                if (MODE == 1) {
+                    double rx;   // the stored record: the cell; zeros where there is none (the stay value of a top row is -1e300 and stays so)
+                    asm("v_max_f64 %0, %1, 0" : "=v"(rx) : "v"(nmx));
+                    *(PS_GLOBAL v2d*)(recp + (size_t)r * (16 * NL)) = (v2d){rx, act ? ns : 0.0};
+                    crun = fmax(crun, rx);
+                }
+                if (MODE == 2) {
+                    if (DEFER_REC) {
+                        pnm[r] = nm; pns[r] = ns;
+                        pmask |= (act && kept) ? (1u << r) : 0u;
+                    } else if (act && kept) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){nm, ns};   // (a cell in band: nm >= 0)
+                    crun = fmax(crun, nmx);
+                }
+                if (DIR == 0) {
+                    const bool gt = nmx > lbest;
+                    asm("v_max_f64 %0, %1, %2" : "=v"(lbest) : "v"(lbest), "v"(nmx));   // (= gt ? nmx : lbest: one v_max instead of two selects; no canonicalisation of the operands)
+                    lbr = gt ? r : lbr;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bot_m = um; bot_s = us; bot_e = ue;
+            if (DIR == 0) lbt = lbest > lbefore ? t : lbt;
+            if (MODE) atomicMax(&ring[(unsigned)j & (RING - 1)], (unsigned long long)__double_as_longlong(crun));   // (scores >= 0 order like their bit patterns; 0 is a no-op)
+            if (MODE && t >= next_flush) {
+                // the maxima of completed columns: everything left of the column the highest strip in band is working on (every wave's
+                // contributions to them were made in earlier steps, i.e. before the barrier this step started behind)
+                const int jdone = min(t - QHI[t], C + 1);
+                for (int col = flushed + lane; col < jdone; col += NL) {
+                    unsigned long long* e = &ring[(unsigned)col & (RING - 1)];
+                    const unsigned long long v = *e;
+                    *e = 0ull;
+                    gcmax[col] = __longlong_as_double((long long)v);
+                }
+                flushed = max(flushed, jdone);
+                next_flush = t + 64;
+            }
+        } else {
+            bot_m = NINF; bot_s = NINF; bot_e = NINF;
+        }
+        if (NW > 1) {
+            if (l63) {
+                double* h = hand + ((t & 1) * NW + wv) * HAND_DOUBLES;
+                *(v2d*)h = (v2d){bot_m, bot_s};
+                if (DIR) h[2] = bot_e;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        ql0 = ql1; ql1 = ql2; ql2 = ql3;
+    };
+
+    // steps 1 .. T - 1, three to a round so that the pipeline stages need no copies; the steps a last round adds behind T - 1 find no
+    // strip in band (qlo = -1 there: Q_PAD) and do nothing
+    for (int t = 1; t < T; t += 3) {
+        step(t, aA, aB, aC);
+        step(t + 1, aB, aC, aA);
+        step(t + 2, aC, aA, aB);
+    }
+    put_pending(T - 1 + (3 - (T - 1) % 3) % 3);   // (the last step run: never live unless it is T - 1 itself)
+    if (DIR == 0 && qcur >= 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
+    if (MODE)
+        for (int col = flushed + lane; col <= C; col += NL) gcmax[col] = __longlong_as_double((long long)ring[(unsigned)col & (RING - 1)]);
+}
+
+// launchers of the multi-wave forms (ps_sweepw.hip); false: no such build
+bool sweepw_launch(Runtime* rt, const BatchD& b, const SweepD& sw, int K, int NW);
+
+}  // namespace ps
+#endif

@@ -31,10 +31,12 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-# Forward-only alignment batches have two kernels (include/poreseq_hip.h, ps_set_sweep_min): one wavefront per alignment
-# (k_sweep, default from 400 alignments on) and one workgroup per alignment (k_fill).  The kernel-level parity modules run
-# every gpu test under both; the other gpu tests run the default, the large golden schedules k_sweep throughout.
+# The DP fills have two kernel families (include/poreseq_hip.h, ps_set_sweep_min / ps_set_sweep_form): strip sweeps — one, two or
+# four wavefronts per alignment and direction (k_sweep / k_sweeps / k_sweep2 and their _w builds, ps_sweep.hip, ps_sweepw.hip) — and
+# one workgroup per alignment with skewed matrices (k_fill).  The kernel-level parity modules run every gpu test under all four;
+# the other gpu tests run the library's own choice, the large golden schedules the strip sweeps throughout.
 _BOTH_KERNELS = ("test_hip_parity", "test_hip_variant")
+_FWD_KERNELS = {"sweep": 1, "sweep_w2": 2, "sweep_w4": 4, "fill": 0}    # name -> wavefronts per sweep (0: k_fill)
 
 
 def pytest_generate_tests(metafunc):
@@ -42,20 +44,23 @@ def pytest_generate_tests(metafunc):
     if mod in _BOTH_KERNELS and metafunc.definition.get_closest_marker("gpu"):
         if "fwd_kernel" not in metafunc.fixturenames:
             metafunc.fixturenames.append("fwd_kernel")
-        metafunc.parametrize("fwd_kernel", ["sweep", "fill"], indirect=True)
+        metafunc.parametrize("fwd_kernel", list(_FWD_KERNELS), indirect=True)
 
 
 @pytest.fixture
 def fwd_kernel(request):
     from poreseq_amd import _capi
     api = _capi.load_hip()
-    api.set_sweep_min(0 if request.param == "sweep" else 1 << 30)
-    api.set_sweep2_min(0 if request.param == "sweep" else 1 << 30)
-    api.set_sparse_min(0 if request.param == "sweep" else 1 << 30)
+    nw = _FWD_KERNELS[request.param]
+    api.set_sweep_min(0 if nw else 1 << 30)
+    api.set_sweep2_min(0 if nw else 1 << 30)
+    api.set_sparse_min(0 if nw else 1 << 30)
+    api.set_sweep_form(0, nw)
     yield request.param
     api.set_sweep_min(-1)
     api.set_sweep2_min(-1)
     api.set_sparse_min(-1)
+    api.set_sweep_form(0, 0)
 
 
 @pytest.fixture

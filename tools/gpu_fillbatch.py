@@ -28,5 +28,7 @@ t = time.time()
 N = 4
 for rep in range(N): once()
 dt = (time.time() - t) / N
-print("R=%d mode=%s pair_min=%s: %.2f ms/call; fill prof (ms, launches, bytes) %s" % (
-    R, mode, os.environ.get("PORESEQ_DEBUG_PAIR_MIN", "default"), 1e3 * dt, api.prof_get("fill")))
+f, s = api.prof_get("fill"), api.prof_get("sweep")
+print("R=%d mode=%s form=%s pair_min=%s: %.2f ms/call; fill %.2f ms x %d launches; sweep %.2f ms x %d launches (w2 %d, w4 %d)" % (
+    R, mode, os.environ.get("PORESEQ_SWEEP_FORM", "auto"), os.environ.get("PORESEQ_DEBUG_PAIR_MIN", "default"), 1e3 * dt,
+    f[0] / max(f[1], 1), f[1], s[0] / max(s[1], 1), s[1], api.prof_get("sweep_w2")[1], api.prof_get("sweep_w4")[1]))
