@@ -827,9 +827,12 @@ static SweepForm pick_form(int W, int nsweeps, bool fastdiv) {
         for (int nw = fastdiv ? fnw : 1; nw >= 1; nw >>= 1) { f = sweep_guess_form(W, nw); if (f.ok()) return f; }
         return f;
     }
+    // Two wavefronts per sweep by default: the SIMD time of one (K = 10) in half the time and three wavefronts per SIMD instead of two
+    // (measured: 2 400 sweeps of 10 kb in 50 ms against 58; 20 in 13 ms against 23).  Four — a quarter more SIMD time, 11 ms — only for
+    // a lone driver thread's small launches: with several lock-step batches in flight the chip is shared and SIMD time is what counts.
     static const int nw_env = getenv("PORESEQ_SWEEP_NW") ? atoi(getenv("PORESEQ_SWEEP_NW")) : 0;       // tuning: wavefronts per sweep
-    static const int w4_max = getenv("PORESEQ_SWEEP_W4_MAX") ? atoi(getenv("PORESEQ_SWEEP_W4_MAX")) : 192;   // sweeps per launch up to which four wavefronts each pay
-    int nw = nw_env > 0 ? nw_env : (nsweeps <= w4_max ? 4 : 2);
+    static const int w4_max = getenv("PORESEQ_SWEEP_W4_MAX") ? atoi(getenv("PORESEQ_SWEEP_W4_MAX")) : 256;   // sweeps per launch up to which four wavefronts each pay
+    int nw = nw_env > 0 ? nw_env : (live_runtimes() <= 1 && nsweeps <= w4_max ? 4 : 2);
     if (!fastdiv) nw = 1;                                         // (the multi-wavefront builds exist with tabulated reciprocals only)
     for (; nw >= 1; nw >>= 1) {
         f = sweep_guess_form(W, nw);
@@ -1290,7 +1293,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         if (!K) sparse = false;
         njobs_all += a->E;
         for (int e = 0; e < a->E && sparse; e++)
-            sparse_bytes += 1.15 * sweep_job_bytes(a->n[e], C, sweep_guess_form(a->par.realign_width, 1)) + 16.0 * (plan[k].nkeep[0] + plan[k].nkeep[1]) * (std::min(2 * a->par.realign_width + 1, a->n[e]) + 3);
+            sparse_bytes += 1.15 * sweep_job_bytes(a->n[e], C, sweep_guess_form(a->par.realign_width, 1)) + 16.0 * (plan[k].nkeep[0] + plan[k].nkeep[1]) * (std::min(2 * a->par.realign_width + 1, a->n[e]) + 24);
     }
     if (sparse && 2 * njobs_all < sparse_min()) sparse = false;
     if (tk.on) {

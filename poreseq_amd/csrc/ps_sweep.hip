@@ -367,7 +367,9 @@ int sweep_prepare(Runtime* rt, Batch& bt, SweepForm f) {
         JobD& j = bt.jobs[k];
         j.K = nd == 2 ? (bt.sparse ? -1 : K) : 0;
         j.NL = NL;
-        if (bt.sparse) j.pitch = (std::min(2 * j.W + 1, j.n0) + 3) & ~1;   // rows of the widest band (+ slack), even: 32-byte aligned columns
+        // kept columns: rows of the widest band + K - 1 records of padding on either side (a lane stores all K rows of its strip: those
+        // outside the band land there), even: 32-byte aligned columns
+        if (bt.sparse) j.pitch = (std::min(2 * j.W + 1, j.n0) + 2 * (K - 1) + 3) & ~1;
         for (int d = 0; d < nd; d++) {
             SweepJob s;
             s.Q = (j.n0 + K - 1) / K;
@@ -376,7 +378,7 @@ int sweep_prepare(Runtime* rt, Batch& bt, SweepForm f) {
             s.q_off = q_tot; q_tot += s.T + Q_PAD;
             s.sb_off = sb_tot; if (d == 0) sb_tot += std::max(s.Q, 1);
             s.codes_off = code_tot; if (d == 0) code_tot += (int64_t)s.T * NL * K;
-            if (nd == 2 && bt.sparse) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)bt.nkeep[2 * k + d] * j.pitch; }
+            if (nd == 2 && bt.sparse) { j.mat_off[d] = rec_tot + (K - 1); rec_tot += (int64_t)bt.nkeep[2 * k + d] * j.pitch + 2 * K; }
             else if (nd == 2) { j.mat_off[d] = rec_tot; rec_tot += (int64_t)s.T * NL * K; }
             maxT = std::max(maxT, s.T);
             sj[k * nd + d] = s;

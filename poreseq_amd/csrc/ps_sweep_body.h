@@ -87,24 +87,30 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     struct Ahead { v4i bd; int sp, sc, kc; };   // bd = {p0, p1, i0, i1} of columns j - 1, j; sp / sc = 5-mer of column j - 1 / j; kc: kept-column index (MODE 2)
     gcip keep = (gcip)uni_ptr(J.keep[DIR]);
     const int pitch = uni(J.pitch);
+    // (every per-lane address below is a wave-uniform base in scalar registers + an unsigned 32-bit byte offset: the `saddr` form of
+    //  the global instructions, one VALU instruction per address instead of four of 64-bit arithmetic)
+    const PS_GLOBAL char* band_c = (const PS_GLOBAL char*)band;
+    const PS_GLOBAL char* st_c = (const PS_GLOBAL char*)(DIR == 0 ? st - 1 : st);   // forward: entry j - 1 = the pair of columns j - 1, j
+    const PS_GLOBAL char* keep_c = (const PS_GLOBAL char*)keep;
+    const PS_GLOBAL char* levs_c = (const PS_GLOBAL char*)levs;
     auto fetch = [&](int tt, int ql) -> Ahead {
         const int q = ql + ((lane - ql) & (NL - 1));
         const int j = clampi(tt - q, 1, max(C, 1));   // (a sequence without a 5-mer has no live step; its prefetches still need an address)
         Ahead a;
-        a.bd = *(const PS_GLOBAL v4i_a4*)(band + 2 * (j - 1));
+        a.bd = *(const PS_GLOBAL v4i_a4*)(band_c + (unsigned)(8 * (j - 1)));
         typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));
         if (DIR == 0) {
-            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (j - 2));   // (ints of -1 around the list: column 0 reads as invalid)
+            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st_c + (unsigned)(4 * (j - 1)));   // (ints of -1 around the list: column 0 reads as invalid)
             a.sp = s2.x; a.sc = s2.y;
         } else {                                                          // backward column j holds states[C - j]
-            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st + (C - j));
+            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st_c + (unsigned)(4 * (C - j)));
             a.sc = s2.x; a.sp = s2.y;
         }
-        a.kc = MODE == 2 ? keep[j] : -1;
+        a.kc = MODE == 2 ? *(const PS_GLOBAL int*)(keep_c + (unsigned)(4 * j)) : -1;
         return a;
     };
     auto model_row = [&](int state, double (&m)[8]) {
-        const PS_GLOBAL v2d* row = (const PS_GLOBAL v2d*)(model + (size_t)(unsigned)max(state, 0) * MODEL_ROW_BYTES);
+        const PS_GLOBAL v2d* row = (const PS_GLOBAL v2d*)(model + (unsigned)max(state, 0) * (unsigned)MODEL_ROW_BYTES);
         const v2d q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
         m[0] = q0.x; m[1] = q0.y; m[2] = q1.x; m[3] = q1.y; m[4] = q2.x; m[5] = q2.y; m[6] = q3.x; m[7] = q3.y;
     };
@@ -149,7 +155,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             qlev = qn;
 #pragma unroll
             for (int r = 0; r < K; r++) {
-                const v4d v = levs[min(qn * K + r, n0 - 1)];
+                const v4d v = *(const PS_GLOBAL v4d*)(levs_c + (unsigned)(32 * min(qn * K + r, n0 - 1)));
                 lev[r][0] = v.x; lev[r][1] = v.y; lev[r][2] = v.z; lev[r][3] = v.w;
             }
         }
@@ -164,17 +170,17 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     bool pend = false;                                               // (uniform) the previous step was live: it has stores waiting
     unsigned cwp[(K + 3) / 4];                                       // its codes, four to a register
     double pnm[DEFER_REC ? K : 1], pns[DEFER_REC ? K : 1];           // its kept-column records
-    unsigned pmask = 0u;                                             // rows of them to store
-    int poff = 0;                                                    // byte offset of the strip's first row in the record pool
+    bool pkept = false;                                              // the lane's column of that step is kept and its strip meets the band
+    unsigned poff = 0u;                                              // byte offset of the strip's first row in the record pool
 #pragma unroll
     for (int w = 0; w < (K + 3) / 4; w++) cwp[w] = 0u;
     auto put_codes = [&](int tp, const unsigned (&cw)[(K + 3) / 4]) {   // the codes of step tp: per row group one coalesced store
-        PS_GLOBAL unsigned char* dst = codes + (size_t)tp * (NL * K);
+        PS_GLOBAL unsigned char* dst = codes + (size_t)tp * (NL * K);      // (uniform)
         int r0 = 0;
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             const int sz = plane_sz(K - r0);
-            PS_GLOBAL unsigned char* p = dst + NL * r0 + lane * sz;
+            PS_GLOBAL unsigned char* p = dst + (unsigned)(NL * r0 + lane * sz);
             if (sz == 16) {
                 v4i v;
                 v.x = cw[r0 / 4]; v.y = cw[r0 / 4 + 1]; v.z = cw[r0 / 4 + 2]; v.w = cw[r0 / 4 + 3];
@@ -199,11 +205,10 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         if (!pend) return;
         if (DIR == 0) put_codes(tp, cwp);
         if (DEFER_REC) {
-            if (pmask) {
-                PS_GLOBAL char* recp = rec + (int64_t)poff;
+            if (pkept) {
+                PS_GLOBAL char* recp = rec - 16 * (K - 1) + poff;
 #pragma unroll
-                for (int r = 0; r < K; r++)
-                    if ((pmask >> r) & 1u) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){pnm[r], pns[r]};
+                for (int r = 0; r < K; r++) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){pnm[r], pns[r]};
             }
         }
     };
@@ -223,18 +228,22 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         }
         const int ql3 = QLO[t + 3];                                  // (one step further ahead than it is needed: the scalar load's latency stays off the step)
         a2 = fetch(t + 2, ql2);
-        double hm = NINF, hs = NINF, he = NINF;                      // (NW > 1) what the previous wave's lane 63 left at the end of step t - 1
-        if (NW > 1) {
-            const double* h = hand + (((t - 1) & 1) * NW + pw) * HAND_DOUBLES;
-            const v2d hv = *(const v2d*)h;
-            hm = hv.x; hs = hv.y;
-            if (DIR) he = h[2];
-        }
         __builtin_amdgcn_sched_barrier(0);                           // (the step's loads are issued before its first emission waits for the model row)
-        // emissions of the lane's K cells first: the model row is then free to receive the next column's (one step of lead)
+        // emissions of the lane's K cells first: the model row is then free to receive the next column's (one step of lead).  NW > 1:
+        // the waves meet between the emissions and the recurrences — the only part of a step that needs another wave's results — so
+        // a wave that runs late by less than its emissions delays nobody; the hand-off record is read behind the barrier, under the
+        // last emission
         double ov[K];
+        double hm = NINF, hs = NINF, he = NINF;                      // (NW > 1) what the previous wave's lane 63 left at the end of step t - 1
 #pragma unroll
         for (int r = 0; r < K; r++) {
+            if (NW > 1 && r == K - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const double* h = hand + (((t - 1) & 1) * NW + pw) * HAND_DOUBLES;
+                const v2d hv = *(const v2d*)h;
+                hm = hv.x; hs = hv.y;
+                if (DIR) he = h[2];
+            }
             ov[r] = emission8<FD>(mr, lev[r], log2pi, off);
             // (pinned here: left to itself the compiler sinks the emissions into the `live` block below, behind the next model row's
             //  loads — which then need registers of their own, a copy at the end of the step and a full `s_waitcnt vmcnt(0)` for it)
@@ -260,11 +269,16 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             double crun = 0.0;                                       // (MODE > 0) the lane's share of its column's maximum
             PS_GLOBAL char* recp = rec + ((size_t)t * K * NL + lane) * 16;
             const bool kept = MODE == 2 && a0.kc >= 0 && j >= 1 && j <= C;
+            // (MODE 2) a lane whose column is kept stores all K rows of its strip when the strip meets the column's band: a row outside
+            // the band lands in the K - 1 records of padding in front of / behind the column's band (sweep_prepare), which nobody reads
+            const bool kstore = kept && ra < K && rb >= 0;
             if (MODE == 2) {
                 // records of the lane's column: row i of the band [i0, i1] at REC[kc][i - i0]; recp = the strip's first row
-                const int64_t ro = ((int64_t)a0.kc * pitch + (base - a0.bd.z)) * 16;
-                recp = rec + ro;
-                if (DEFER_REC) { poff = (int)ro; pmask = 0u; }      // (kept columns of one direction of one job: < 2^31 bytes, sweep_prepare)
+                // (offsets from K - 1 records in front of the pool's first column, where its padding starts: never negative for a strip
+                //  that meets the band; kept columns of one direction of one job: < 2^31 bytes)
+                const unsigned ro = (unsigned)((a0.kc * pitch + (base - a0.bd.z) + (K - 1)) * 16);
+                recp = rec - 16 * (K - 1) + ro;
+                if (DEFER_REC) { poff = ro; pkept = kstore; }
                 if (kept && !valid)   // a kept column without a 5-mer: its band reads as zeros (cpp/Alignment.cpp:162-163)
                     for (int r = max(0, a0.bd.z - base); r <= min(K - 1, a0.bd.w - base); r++) *(PS_GLOBAL v2d*)(recp + (size_t)r * 16) = (v2d){0.0, 0.0};
             }
@@ -329,10 +343,8 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                     crun = fmax(crun, rx);
                 }
                 if (MODE == 2) {
-                    if (DEFER_REC) {
-                        pnm[r] = nm; pns[r] = ns;
-                        pmask |= (act && kept) ? (1u << r) : 0u;
-                    } else if (act && kept) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){nm, ns};   // (a cell in band: nm >= 0)
+                    if (DEFER_REC) { pnm[r] = nm; pns[r] = ns; }
+                    else if (kstore) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){nm, ns};   // (a cell in band: nm >= 0)
                     crun = fmax(crun, nmx);
                 }
                 if (DIR == 0) {
@@ -361,26 +373,36 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         } else {
             bot_m = NINF; bot_s = NINF; bot_e = NINF;
         }
-        if (NW > 1) {
-            if (l63) {
-                double* h = hand + ((t & 1) * NW + wv) * HAND_DOUBLES;
-                *(v2d*)h = (v2d){bot_m, bot_s};
-                if (DIR) h[2] = bot_e;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (NW > 1 && l63) {
+            double* h = hand + ((t & 1) * NW + wv) * HAND_DOUBLES;
+            *(v2d*)h = (v2d){bot_m, bot_s};
+            if (DIR) h[2] = bot_e;
         }
         ql0 = ql1; ql1 = ql2; ql2 = ql3;
     };
 
-    // steps 1 .. T - 1, three to a round so that the pipeline stages need no copies; the steps a last round adds behind T - 1 find no
-    // strip in band (qlo = -1 there: Q_PAD) and do nothing
-    for (int t = 1; t < T; t += 3) {
-        step(t, aA, aB, aC);
-        step(t + 1, aB, aC, aA);
-        step(t + 2, aC, aA, aB);
+#ifndef PS_SWEEP_UNROLL_MAXK
+#define PS_SWEEP_UNROLL_MAXK 5
+#endif
+    if (K <= PS_SWEEP_UNROLL_MAXK) {
+        // steps 1 .. T - 1, three to a round so that the pipeline stages need no copies; the steps a last round adds behind T - 1 find
+        // no strip in band (qlo = -1 there: Q_PAD) and do nothing.  (Taller strips keep one copy of the body: three of K = 10's
+        // would be most of the instruction cache two CUs share.)
+        for (int t = 1; t < T; t += 3) {
+            step(t, aA, aB, aC);
+            step(t + 1, aB, aC, aA);
+            step(t + 2, aC, aA, aB);
+        }
+        put_pending(T - 1 + (3 - (T - 1) % 3) % 3);   // (the last step run: never live unless it is T - 1 itself)
+    } else {
+        for (int t = 1; t < T; t++) {
+            step(t, aA, aB, aC);
+            aA = aB; aB = aC;
+        }
+        put_pending(T - 1);
     }
-    put_pending(T - 1 + (3 - (T - 1) % 3) % 3);   // (the last step run: never live unless it is T - 1 itself)
     if (DIR == 0 && qcur >= 0 && lbest > 0.0) { StripBest sbv; sbv.v = lbest; sbv.i = qcur * K + 1 + lbr; sbv.j = lbt - qcur; SB[qcur] = sbv; }
+    if (NW > 1 && MODE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (every wave's last column maxima are in the ring)
     if (MODE)
         for (int col = flushed + lane; col <= C; col += NL) gcmax[col] = __longlong_as_double((long long)ring[(unsigned)col & (RING - 1)]);
 }

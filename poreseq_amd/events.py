@@ -2,8 +2,9 @@
 
 The native layer reads exactly what the reference's `PythonToEvents` reads
 (pyx:99-129): float64 1-D `mean, stdv, ref_align, ref_like`, `sequence`, and
-`model.{level_mean, level_stdv, sd_mean, sd_stdv, complement, prob_*}`.  The file formats themselves (fast5 through h5py, BAM
-through pysam: poreseq/EventData.py:116-128, LoadData.py:81-90) stay out of scope — neither library is in this image — but everything
+`model.{level_mean, level_stdv, sd_mean, sd_stdv, complement, prob_*}`.  The file formats are read through h5py / pysam where those
+are installed (`PSEvent.from_fast5`, `poreseq_amd.loaddata.events_from_bam`: poreseq/EventData.py:113-128, LoadData.py:81-90 — thin
+readers with guarded imports; neither library is in the build image, the tests run them on stand-in modules) and everything
 the reference computes from the parsed tables is here: `PSEvent.from_basecall` (model scaling, drift, the k-mer walk that seeds
 ref_align: EventData.py:130-175), `flip` (:182-224), `mapaligns` (:226-256), `setparams` (:288-312); the read selection of
 `EventsFromBAM` on parsed records is `poreseq_amd.loaddata`.  Vectors: tests/golden/frontend.npz, made by running the reference's own
@@ -91,6 +92,32 @@ class PSEvent:
         if m.complement:
             ev.flip(False)
         return ev
+
+    @classmethod
+    def from_fast5(cls, filename, typ):
+        """The reference's `PSEvent(filename, typ)` (EventData.py:100-175): the template ('t') or complement ('c') strand of an
+        R7 2D-basecalled fast5 file.  Only the five dataset reads are here (EventData.py:113-128: `Events`, `Model`, the
+        `basecall_1d_*` summary attributes, the 2D `Fastq` and `Alignment`); everything computed from them is `from_basecall`.
+        Needs h5py, which this package does not depend on: without it the call fails with an ImportError that says so."""
+        try:
+            import h5py
+        except ImportError as e:
+            raise ImportError("PSEvent.from_fast5 reads fast5 files through h5py, which is not installed; "
+                              "PSEvent.from_basecall takes the parsed tables") from e
+        loc = "complement" if str(typ)[0] == "c" else "template"
+        base = "/Analyses/Basecall_2D_000/"
+        f = h5py.File(filename, "r")
+        try:
+            fastq = f[base + "BaseCalled_2D/Fastq"][()]
+            fastq = fastq.decode() if isinstance(fastq, bytes) else str(fastq)
+            aldata = f[base + "BaseCalled_2D/Alignment"]
+            return cls.from_basecall(f[base + "BaseCalled_" + loc + "/Events"], f[base + "BaseCalled_" + loc + "/Model"],
+                                     f[base + "Summary/basecall_1d_" + loc].attrs, fastq.split("\n")[1],
+                                     aldata[loc], aldata["kmer"], complement=(loc == "complement"))
+        finally:
+            close = getattr(f, "close", None)
+            if close is not None:
+                close()
 
     def copy(self):
         return _copy.deepcopy(self)

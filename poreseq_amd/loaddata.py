@@ -1,12 +1,15 @@
-"""Read selection of the reference's BAM front end on PARSED records (poreseq/LoadData.py:67-153).
+"""The reference's BAM front end (poreseq/LoadData.py:10-153).
 
-pysam is not in this image, so nothing here opens a BAM file: `events_from_bam_records` takes what `AlignmentFile.fetch` would have
-returned — any objects with `query_name`, `is_reverse`, `cigar`, `get_overlap(start, end)` and `get_aligned_pairs()` (pysam's own
+`events_from_bam` / `load_aligned_events` open the files the way the reference does (pysam for the BAM file, h5py for the fast5
+files: guarded imports, neither is in the build image).  The work is in `events_from_bam_records`, which takes what
+`AlignmentFile.fetch` returns — any objects with `query_name`, `is_reverse`, `cigar`, `get_overlap(start, end)` and `get_aligned_pairs()` (pysam's own
 AlignedSegment has them) — and a callable that loads one strand of one read (`poreseq_amd.events.PSEvent.from_basecall` on the
 tables of its fast5 file).  What it does with them is the reference's: overlap filter, descending-overlap order, one alignment per
 read name up to max_coverage, hard-clip and region offsets of the aligned pairs, reverse-strand flip, `mapaligns`.
 Vectors: tests/golden/frontend.npz (the reference's function run on stand-in records, tests/golden/make_golden_frontend.py).
 """
+import os
+
 import numpy as np
 
 
@@ -61,3 +64,60 @@ def events_from_bam_records(records, load_event, start, end, params):
     if not events:
         raise Exception("No aligned reads found!")
     return events
+
+
+def events_from_bam(eventdir, bamfile, reginfo, params):
+    """EventsFromBAM (LoadData.py:67-153): the events of the reads a BAM file aligns to `reginfo` (name / start / end; a missing name
+    is taken from a single-reference BAM file and written back, as the reference does), each strand loaded from
+    `eventdir/<query name>` by `PSEvent.from_fast5`.  Needs pysam (and h5py): without it the call fails with an ImportError that says so."""
+    try:
+        import pysam
+    except ImportError as e:
+        raise ImportError("events_from_bam reads BAM files through pysam, which is not installed; "
+                          "events_from_bam_records takes the parsed records") from e
+    from .events import PSEvent
+    bam = pysam.AlignmentFile(bamfile, "rb")
+    if reginfo.name is None:
+        if bam.nreferences > 1:
+            raise Exception("Multiple references in BAM, one must be specified!")
+        reginfo.name = bam.references[0]
+    records = list(bam.fetch(reference=reginfo.name, start=reginfo.start, end=reginfo.end))
+    return events_from_bam_records(records, lambda name, loc: PSEvent.from_fast5(os.path.join(eventdir, name), loc),
+                                   reginfo.start, reginfo.end, params)
+
+
+def load_reference(fastafile, refname=None):
+    """LoadReference (LoadData.py:53-65) without Biopython: the named record of a FASTA file (the only one when no name is given)."""
+    refs, name = {}, None
+    with open(fastafile) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith(">"):
+                name = line[1:].split()[0] if len(line) > 1 else ""
+                refs[name] = []
+            elif line and name is not None:
+                refs[name].append(line)
+    if refname is None:
+        if len(refs) != 1:
+            raise Exception("Multiple references in fasta, must specify one")
+        refname = next(iter(refs))
+    return "".join(refs[refname])
+
+
+def load_aligned_events(fastafile, bamfile, eventdir, reginfo, params, psalign=None):
+    """LoadAlignedEvents (LoadData.py:10-51): the PSAlign of one region — reference slice, the events aligned to it, the parameters
+    (`setparams` on every event).  `psalign`: the class to build (default: this package's drop-in PSAlign)."""
+    refseq = load_reference(fastafile, reginfo.name)
+    if reginfo.start is None and reginfo.end is None:
+        reginfo.start, reginfo.end = 0, len(refseq)
+    events = events_from_bam(eventdir, bamfile, reginfo, params)
+    if len(params) > 0:
+        for ev in events:
+            ev.setparams(params)
+    if psalign is None:
+        from .poreseqcpp import PSAlign as psalign
+    pa = psalign()
+    pa.sequence = refseq[reginfo.start:reginfo.end]
+    pa.events = events
+    pa.params = params
+    return pa

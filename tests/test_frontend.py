@@ -104,3 +104,108 @@ def test_events_from_bam_records_equal_the_reference_function():
         loaddata.events_from_bam_records(recs, loader, start, end, dict(params, min_coverage=9))
     with pytest.raises(Exception, match="No aligned reads found!"):
         loaddata.events_from_bam_records(recs, lambda n, l: (_ for _ in ()).throw(IOError()), start, end, params)
+
+
+# ---- the file half (EventData.py:113-128, LoadData.py:81-90) on stand-ins for the h5py / pysam modules -------------------------------
+class _Dataset:
+    """what the readers use of an h5py Dataset: field / index access, [()] for scalars, .attrs"""
+    def __init__(self, value, attrs=None):
+        self.value, self.attrs = value, attrs or {}
+
+    def __getitem__(self, k):
+        return self.value if isinstance(k, tuple) and k == () else self.value[k]
+
+
+def _fake_fast5(tag):
+    base = "/Analyses/Basecall_2D_000/"
+    store = {}
+    for name in ("template", "complement"):
+        attrs = {k: Z["%s_in_%s_attr_%s" % (tag, name, k)][()] for k in ("shift", "scale", "scale_sd", "drift", "var", "var_sd", "model_file")}
+        store[base + "BaseCalled_%s/Events" % name] = _Dataset(Z["%s_in_%s_events" % (tag, name)])
+        store[base + "BaseCalled_%s/Model" % name] = _Dataset(Z["%s_in_%s_model" % (tag, name)])
+        store[base + "Summary/basecall_1d_%s" % name] = _Dataset(None, attrs)
+    seq = str(Z["%s_in_sequence" % tag])
+    store[base + "BaseCalled_2D/Fastq"] = _Dataset(("@read\n%s\n+\n%s\n" % (seq, "!" * len(seq))).encode())   # h5py >= 3 hands out bytes
+    store[base + "BaseCalled_2D/Alignment"] = _Dataset(Z["%s_in_alignment" % tag])
+    return store
+
+
+def _h5py_standin():
+    import types
+
+    def File(filename, mode):
+        tag = os.path.basename(filename).split(".")[0]
+        if "%s_in_sequence" % tag not in Z.files:
+            raise IOError("unable to open file: %s" % filename)
+        return _fake_fast5(tag)
+    return types.SimpleNamespace(File=File)
+
+
+@pytest.mark.parametrize("loc", ["t", "c"])
+def test_from_fast5_reads_the_reference_s_five_datasets(monkeypatch, loc):
+    import sys
+    monkeypatch.setitem(sys.modules, "h5py", _h5py_standin())
+    for tag in (str(n).split(".")[0] for n in Z["event_names"]):
+        same(PSEvent.from_fast5("/data/run7/%s.fast5" % tag, loc), "%s_%s" % (tag, loc))
+    with pytest.raises(IOError):
+        PSEvent.from_fast5("/data/run7/missing.fast5", loc)
+
+
+def test_events_from_bam_opens_the_files_like_the_reference(monkeypatch, tmp_path):
+    import sys, types
+    from poreseq_amd.util import RegionInfo
+    recs = [Rec(k) for k in range(len(Z["bam_rec_name"]))]
+    start, end = (int(x) for x in Z["bam_region"])
+    seen = {}
+
+    class AlignmentFile:
+        nreferences, references = 1, ("chrT",)
+
+        def __init__(self, fn, mode):
+            seen["open"] = (fn, mode)
+
+        def fetch(self, reference=None, start=None, end=None):
+            seen["fetch"] = (reference, start, end)
+            return iter(recs)
+    monkeypatch.setitem(sys.modules, "pysam", types.SimpleNamespace(AlignmentFile=AlignmentFile))
+    monkeypatch.setitem(sys.modules, "h5py", _h5py_standin())
+    mo, mc, mn = (int(x) for x in Z["bam_params"])
+    params = {"min_overlap": mo, "max_coverage": mc, "min_coverage": mn, "skip_t": 0.07, "stay_c": 0.12}
+    reg = RegionInfo("%d:%d" % (start, end))
+    events = loaddata.events_from_bam("/data/run7", "aln.bam", reg, params)
+    assert seen == {"open": ("aln.bam", "rb"), "fetch": ("chrT", start, end)} and reg.name == "chrT"    # the name is written back (LoadData.py:84-87)
+    assert len(events) == int(Z["bam_n_events"])
+    for k, ev in enumerate(events):
+        same(ev, "bam_ev%d" % k)
+    AlignmentFile.nreferences, AlignmentFile.references = 2, ("chrT", "chrU")
+    with pytest.raises(Exception, match="Multiple references in BAM"):
+        loaddata.events_from_bam("/data/run7", "aln.bam", RegionInfo("%d:%d" % (start, end)), params)
+    # LoadAlignedEvents: reference slice, events, setparams on every event (LoadData.py:10-51)
+    AlignmentFile.nreferences, AlignmentFile.references = 1, ("chrT",)
+    ref = "".join("ACGT"[k] for k in np.random.default_rng(5).integers(0, 4, 700))
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chrT some description\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+
+    class PA:
+        pass
+    pa = loaddata.load_aligned_events(str(fa), "aln.bam", "/data/run7", RegionInfo("chrT:%d:%d" % (start, end)), params, psalign=PA)
+    assert pa.sequence == ref[start:end] and pa.params is params and len(pa.events) == int(Z["bam_n_events"])
+    for ev in pa.events:
+        assert (ev.model.prob_stay == 0.12) == ev.model.complement and (ev.model.prob_skip == 0.07) == (not ev.model.complement)
+    whole = loaddata.load_aligned_events(str(fa), "aln.bam", "/data/run7", RegionInfo(None), dict(params, min_coverage=0), psalign=PA)
+    assert whole.sequence == ref
+    (tmp_path / "two.fa").write_text(">a\nACGT\n>b\nGGCC\n")
+    assert loaddata.load_reference(str(tmp_path / "two.fa"), "b") == "GGCC"
+    with pytest.raises(Exception, match="Multiple references in fasta"):
+        loaddata.load_reference(str(tmp_path / "two.fa"))
+
+
+def test_file_readers_say_which_library_is_missing(monkeypatch):
+    import sys
+    from poreseq_amd.util import RegionInfo
+    monkeypatch.setitem(sys.modules, "h5py", None)      # (None in sys.modules: the import fails, installed or not)
+    monkeypatch.setitem(sys.modules, "pysam", None)
+    with pytest.raises(ImportError, match="h5py"):
+        PSEvent.from_fast5("x.fast5", "t")
+    with pytest.raises(ImportError, match="pysam"):
+        loaddata.events_from_bam(".", "x.bam", RegionInfo("0:10"), {})
