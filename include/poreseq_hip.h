@@ -212,6 +212,11 @@ int ps_set_sparse_min(int32_t min_sweeps);
  * launch size; PORESEQ_SWEEP_FORM=K,NW).  Returns PS_ERR_BAD_ARG for a form that is not built.
  * Results do not depend on it (the reference has one serial loop per alignment, cpp/Alignment.cpp:83-99). */
 int ps_set_sweep_form(int32_t rows_per_lane, int32_t wavefronts);
+/* The part of the device's memory THIS PROCESS plans for (process-wide; default 1, or PORESEQ_DEVICE_FRACTION): the slabs for full
+ * score matrices, every runtime's share and the ceiling of the device pools are fractions of it.  One process per GPU leaves it
+ * alone; ranks that share a GPU set 1 / (ranks on the device) before their first compute call (poreseq_amd.dist.init does).
+ * fraction <= 0 restores the default; > 1 is PS_ERR_BAD_ARG.  Not part of the reference's interface (its processes share nothing). */
+int ps_set_device_fraction(double fraction);
 
 /* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
  * algorithmic bytes of the named kernel class ("fill" = k_fill, "sweep" = k_sweep / k_sweep2, "score", "viterbi", "sw") since reset. */

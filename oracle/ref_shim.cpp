@@ -227,6 +227,7 @@ int ps_set_sweep_min(int32_t) { return PS_OK; }
 int ps_set_sweep2_min(int32_t) { return PS_OK; }
 int ps_set_sparse_min(int32_t) { return PS_OK; }
 int ps_set_sweep_form(int32_t, int32_t) { return PS_OK; }
+int ps_set_device_fraction(double) { return PS_OK; }
 int ps_info(char* out, int64_t cap) { if (!out || cap <= 0) return PS_ERR_BAD_ARG; const char* s = "cpu checker"; size_t n = strlen(s) < (size_t)cap - 1 ? strlen(s) : (size_t)cap - 1; memcpy(out, s, n); out[n] = 0; return PS_OK; }
 int ps_prof_enable(int32_t) { return PS_OK; }
 int ps_prof_reset(void) { return PS_OK; }

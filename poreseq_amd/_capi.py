@@ -83,6 +83,7 @@ SYMBOLS = {
     "ps_set_sweep2_min": (C.c_int, [C.c_int32]),
     "ps_set_sparse_min": (C.c_int, [C.c_int32]),
     "ps_set_sweep_form": (C.c_int, [C.c_int32, C.c_int32]),
+    "ps_set_device_fraction": (C.c_int, [C.c_double]),
     "ps_prof_enable": (C.c_int, [C.c_int32]),
     "ps_prof_reset": (C.c_int, []),
     "ps_prof_get": (C.c_int, [C.c_char_p, c_dp, c_i64p, c_dp]),
@@ -398,6 +399,10 @@ class CApi:
     def set_sweep_form(self, rows_per_lane, wavefronts=1):
         """the form strip sweeps try first: rows of the band per lane, wavefronts per (alignment, direction); <= 0: the library's choice"""
         self.check(self.lib.ps_set_sweep_form(int(rows_per_lane), int(wavefronts)))
+
+    def set_device_fraction(self, fraction):
+        """the part of the device's memory this process plans for (ranks sharing a GPU: 1 / ranks on it); <= 0: the default"""
+        self.check(self.lib.ps_set_device_fraction(float(fraction)))
 
     def prof_enable(self, on):
         self.check(self.lib.ps_prof_enable(int(on)))   # 1: synchronous per launch, 2: event pairs queued and read by prof_get

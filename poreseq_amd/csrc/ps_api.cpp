@@ -318,6 +318,11 @@ int ps_rand_draw(int64_t n, double* out) {
 int ps_set_sweep_min(int32_t n) { sweep_min_set(n); return PS_OK; }
 int ps_set_sweep2_min(int32_t n) { sweep2_min_set(n); return PS_OK; }
 int ps_set_sparse_min(int32_t n) { sparse_min_set(n); return PS_OK; }
+int ps_set_device_fraction(double f) {
+    if (f > 1.0) return fail(PS_ERR_BAD_ARG, "ps_set_device_fraction: a fraction in (0, 1]; <= 0 restores the default");
+    device_fraction_set(f);
+    return PS_OK;
+}
 int ps_set_sweep_form(int32_t K, int32_t NW) {
     if (K <= 0 && NW > 0 && NW != 1 && NW != 2 && NW != 4) return fail(PS_ERR_BAD_ARG, "ps_set_sweep_form: 1, 2 or 4 wavefronts per sweep");
     if (K > 0 && !sweep_form_exists(K, NW)) return fail(PS_ERR_BAD_ARG, "ps_set_sweep_form: no such form (rows per lane, wavefronts)");

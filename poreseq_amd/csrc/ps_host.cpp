@@ -39,6 +39,7 @@ void Tick::lap(const char* label) {
 // ------------------------------------------------------------------------------------------ runtime
 static size_t trim_idle_runtimes();   // below: hands back the device pools of runtimes no thread owns
 static size_t device_total_bytes();
+static size_t device_plan_bytes();   // this process's part of it (ps_set_device_fraction)
 static std::atomic<long long> g_pool_bytes(0);   // device memory held by the pools of all runtimes
 
 int DBuf::ensure(size_t bytes) {
@@ -49,7 +50,7 @@ int DBuf::ensure(size_t bytes) {
     size_t want = std::max<size_t>(bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30), 1 << 16);   // growth slack, at most 1 GB
     // never into the last 6 % of the device: a launch that finds no memory for the HSA runtime's own needs aborts the process
     // (HSA_STATUS_ERROR_OUT_OF_RESOURCES) — refuse here instead, callers that can cut their batch do so on PS_ERR_NOMEM
-    if (const size_t tot = device_total_bytes()) {
+    if (const size_t tot = device_plan_bytes()) {
         auto over = [&](size_t w) { return (double)g_pool_bytes.load() + (double)w > 0.94 * (double)tot; };
         if (over(want)) want = std::max<size_t>(bytes, 1 << 16);
         if (over(want)) (void)trim_idle_runtimes();
@@ -506,6 +507,20 @@ static size_t device_total_bytes() {
     return tot;
 }
 
+// The part of the device this PROCESS plans for.  One process per GPU (the normal deployment) owns the device: 1.  Several ranks on one
+// device (poreseq_amd.dist.init with more ranks than GPUs; the 8-rank test of the driver's command line on one GPU) each plan for
+// their fraction — ps_set_device_fraction / PORESEQ_DEVICE_FRACTION — so that the slabs, the runtimes' shares and the 94 % guard of
+// the pools add up to one device, not to one device per rank.
+static std::atomic<double> g_dev_fraction(-1.0);
+void device_fraction_set(double f) { g_dev_fraction.store(f > 0.0 && f <= 1.0 ? f : -1.0); }
+double device_fraction() {
+    const double f = g_dev_fraction.load();
+    if (f > 0.0) return f;
+    static const double env = [] { const char* e = getenv("PORESEQ_DEVICE_FRACTION"); const double v = e ? atof(e) : 1.0; return v > 0.0 && v <= 1.0 ? v : 1.0; }();
+    return env;
+}
+static size_t device_plan_bytes() { return (size_t)(device_fraction() * (double)device_total_bytes()); }
+
 // Memory plan of the device (309 GB on an MI355X): 27 % in three slabs for full score matrices (below), 13 % left alone (the HSA
 // runtime aborts the process when a launch finds no memory for its own needs, and hipMalloc rounds: pools that sum to 302 GB left
 // 5 GB free), 60 % to the runtimes.  What a runtime holds follows its share: the matrix pool grows 6 % past it, small forward batches
@@ -515,7 +530,7 @@ static size_t device_total_bytes() {
 // step codes each), of Smith-Waterman batches and of the Viterbi tables.
 double device_share_bytes() {
     if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return g * 1e9; }
-    const size_t tot = device_total_bytes();
+    const size_t tot = device_plan_bytes();
     if (!tot) return 32e9;
     const int nrt = std::max(4, peak_runtimes());
     return std::max(2e9, (0.60 * (double)tot / nrt - 2.5e9) / 1.4);
@@ -540,7 +555,7 @@ static int slab_count() { static const int n = getenv("PORESEQ_SLABS") ? std::ma
 size_t slab_bytes() {
     static const double gb = getenv("PORESEQ_SLAB_GB") ? atof(getenv("PORESEQ_SLAB_GB")) : 0.0;
     if (gb > 0) return (size_t)(gb * 1e9);
-    const size_t tot = device_total_bytes();
+    const size_t tot = device_plan_bytes();
     return tot ? (size_t)(0.09 * (double)tot) : (size_t)24e9;
 }
 // bytes of full matrices one dense call may place: the slab, or PORESEQ_MAX_BATCH_GB when set (tests: tiny budgets)
@@ -599,8 +614,7 @@ static int ensure_matrix_pools(Runtime* rt, const Batch& bt, size_t need_rec, si
     }
     DBuf& rec = rt->buf("rec");
     DBuf& flg = rt->buf("flg");
-    size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
+    size_t tot = device_plan_bytes();
     if (!getenv("PORESEQ_MAX_BATCH_GB") && rec.p && (double)rec.cap > 1.5 * device_share_bytes() + 2e9 && need_rec < rec.cap) {
         PS_HIP(hipStreamSynchronize(rt->stream));
         PS_HIP(hipFree(rec.p)); g_pool_bytes -= (long long)rec.cap; rec.p = nullptr; rec.cap = 0;
@@ -1360,6 +1374,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     if (!sparse && R == 1) for (int e = 0; e < as[0]->E; e++) lone_need += ((double)as[0]->n[e] + as[0]->states.size() + 1 + MAT_FRONT + MAT_BACK) * std::min(1024, 2 * as[0]->par.realign_width + 74) * 36.0;
     if (!sparse && lone_need <= (double)slab_bytes()) {
         PS_TRY(slab_acquire(&slab));
+        if (rt->prof_on) rt->prof["slab"].launches++;   // (dense calls that took a slab: a host-side count)
         slab.drain = rt->stream;
         b.ext = slab.p; b.ext_bytes = R > 1 ? std::min(slab.bytes, (size_t)dense_cap_bytes()) : slab.bytes;
         tk.lap("slab wait");
@@ -1594,8 +1609,8 @@ std::string info_string() {
     size_t nslab = 0, slab_b = 0;
     { std::lock_guard<std::mutex> lk(g_slab_mu); nslab = g_slabs.size(); for (Slab* sl : g_slabs) slab_b += sl->bytes; }
     char buf[512];
-    snprintf(buf, sizeof buf, "; runtimes: %d live, %d peak; share per runtime %.1f GB; slabs for full score matrices: %zu of %d allocated (%.1f GB, %.1f GB each by plan); device pools of this process %.1f GB",
-             live_runtimes(), peak_runtimes(), device_share_bytes() * 1e-9, nslab, slab_count(), slab_b * 1e-9, slab_bytes() * 1e-9, (double)g_pool_bytes.load() * 1e-9);
+    snprintf(buf, sizeof buf, "; device fraction of this process %.3f; runtimes: %d live, %d peak; share per runtime %.1f GB; slabs for full score matrices: %zu of %d allocated (%.1f GB, %.1f GB each by plan); device pools of this process %.1f GB",
+             device_fraction(), live_runtimes(), peak_runtimes(), device_share_bytes() * 1e-9, nslab, slab_count(), slab_b * 1e-9, slab_bytes() * 1e-9, (double)g_pool_bytes.load() * 1e-9);
     return "hip-gfx950; streams: " + why + buf;
 }
 

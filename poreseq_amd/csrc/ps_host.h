@@ -129,6 +129,8 @@ int hwq_mode(std::string* why);   // 1: every stream on one priority level (a ha
 int peak_runtimes();   // most host threads that ever owned a runtime at the same time
 int live_runtimes();   // host threads that currently own a runtime
 int guess_slots(const Align* a);   // anti-diagonal footprint realign() will probably choose
+void device_fraction_set(double f);   // the part of the device this process plans for (several ranks on one GPU); <= 0: PORESEQ_DEVICE_FRACTION, else 1
+double device_fraction();
 double device_share_bytes();   // this runtime's share of the device memory for its own pools (step codes, kept columns, small matrices)
 // a process-wide slab for the full score matrices of one Refine-sized ScoreMutations call (ps_host.cpp)
 struct SlabHold { void* s = nullptr; char* p = nullptr; size_t bytes = 0; hipStream_t drain = nullptr; void release(); ~SlabHold() { release(); } };   // release() drains `drain` first: nothing in flight may still use the slab

@@ -583,6 +583,7 @@ int sw_launch(Runtime* rt, const std::vector<std::pair<const std::string*, const
     if (const char* e = getenv("PORESEQ_SW_PK")) if (atoi(e) == 0) packed = false;
     if (packed) {
         PS_TRY(sw_run_pk(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res));
+        if (rt->prof_on) rt->prof["sw_pk8"].launches++;   // (which fill ran: a host-side count, no event pair)
     } else if (WW == SWW1) {
         switch (K) {
             case 8: PS_TRY((sw_run<8, SWW1>(rt, st, np, nss, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_out, d_res))); break;

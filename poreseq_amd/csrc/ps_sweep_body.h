@@ -232,18 +232,10 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         // emissions of the lane's K cells first: the model row is then free to receive the next column's (one step of lead).  NW > 1:
         // the waves meet between the emissions and the recurrences — the only part of a step that needs another wave's results — so
         // a wave that runs late by less than its emissions delays nobody; the hand-off record is read behind the barrier, under the
-        // last emission
+        // stores of the step before and the loads of the next column's model row
         double ov[K];
-        double hm = NINF, hs = NINF, he = NINF;                      // (NW > 1) what the previous wave's lane 63 left at the end of step t - 1
 #pragma unroll
         for (int r = 0; r < K; r++) {
-            if (NW > 1 && r == K - 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                const double* h = hand + (((t - 1) & 1) * NW + pw) * HAND_DOUBLES;
-                const v2d hv = *(const v2d*)h;
-                hm = hv.x; hs = hv.y;
-                if (DIR) he = h[2];
-            }
             ov[r] = emission8<FD>(mr, lev[r], log2pi, off);
             // (pinned here: left to itself the compiler sinks the emissions into the `live` block below, behind the next model row's
             //  loads — which then need registers of their own, a copy at the end of the step and a full `s_waitcnt vmcnt(0)` for it)
@@ -251,6 +243,14 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             if (r & 1) __builtin_amdgcn_sched_barrier(0);            // two emissions in flight: enough to fill the pipe, few enough to stay in registers
         }
         __builtin_amdgcn_sched_barrier(0);
+        double hm = NINF, hs = NINF, he = NINF;                      // (NW > 1) what the previous wave's lane 63 left at the end of step t - 1
+        if (NW > 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const double* h = hand + (((t - 1) & 1) * NW + pw) * HAND_DOUBLES;
+            const v2d hv = *(const v2d*)h;
+            hm = hv.x; hs = hv.y;
+            if (DIR) he = h[2];
+        }
         put_pending(t - 1);
         load_levels(ql1);
         model_row(a1.sc, mr);

@@ -16,7 +16,9 @@ def init(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("PORESEQ_DEVICE", str(local))   # read by libporeseq_hip when it first touches the GPU
-    _pin_host_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    _pin_host_cores(local, local_world)
+    _share_device(local, local_world)
     force = os.environ.get("PORESEQ_FORCE_PG") == "1"     # tests: exercise the collective path on one GPU
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
@@ -28,6 +30,22 @@ def init(backend=None):
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def _share_device(local, local_world):
+    """More local ranks than GPUs (tests of the N-rank command line on one device; never the production layout): every rank plans its
+    device memory — slabs, runtime shares, pool ceiling — for its fraction of the device it lands on (include/poreseq_hip.h,
+    ps_set_device_fraction), through the environment because the library reads it at its first compute call."""
+    try:
+        ndev = torch.cuda.device_count()             # (counts devices without initialising the GPU)
+    except Exception:
+        ndev = 0
+    if ndev < 1 or local_world <= ndev:
+        return 1.0
+    mine = sum(1 for r in range(local_world) if r % ndev == local % ndev)
+    frac = 1.0 / max(1, mine)
+    os.environ.setdefault("PORESEQ_DEVICE_FRACTION", "%.6f" % frac)
+    return frac
 
 
 def _pin_host_cores(local, local_world):
@@ -231,13 +249,14 @@ def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_e
     step = max(1, int(batch))
     chunks = [mine[k:k + step] for k in range(0, len(mine), step)]
 
+    probe = {}            # the first region's object, built once: it tells the backend and then IS that region (a real loader reads BAM + fast5)
     if mine and in_flight > 1:
         a0, b0 = mine[0][1]
-        probe = make_region_pa(a0, b0)
-        hip_backend = isinstance(probe, PSAlign) and type(probe)._native is PSAlign._native
+        probe[mine[0][0]] = make_region_pa(a0, b0)
+        hip_backend = isinstance(probe[mine[0][0]], PSAlign) and type(probe[mine[0][0]])._native is PSAlign._native
 
     def one(chunk):
-        pas = [make_region_pa(a, b) for _, (a, b) in chunk]
+        pas = [probe.pop(idx) if idx in probe else make_region_pa(a, b) for idx, (a, b) in chunk]
         res = consensus_regions(pas, params, reps=reps)
         return [(idx, seq, np.array([acc])) for (idx, _), (seq, acc) in zip(chunk, res)]
 

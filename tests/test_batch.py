@@ -134,7 +134,7 @@ def test_hip_seed_chunks_are_cut_again_when_the_bands_are_wider_than_guessed():
     assert got == want
     # the strip sweep (forward-only batches): a strip height too small for the band is raised, code pools over the share are split
     got3, err3 = run({"PORESEQ_DEBUG_SWEEP_K": "4", "PORESEQ_MAX_BATCH_GB": "0.02", "PORESEQ_SWEEP_MIN": "0"})
-    assert "K = 4," in err3 and ("K = 6," in err3 or "K = 10," in err3) and "of step codes" in err3
+    assert "K = 4 on 1 wave" in err3 and ("K = 6 on 1 wave" in err3 or "K = 10 on 1 wave" in err3) and "of step codes" in err3
     assert got3 == want
     assert run({"PORESEQ_SWEEP_MIN": "0"})[0] == want    # both kernels: the same results
     got2, err2 = run({"PORESEQ_MAX_BATCH_GB": "0.002"})

@@ -81,9 +81,11 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
 @pytest.mark.gpu
 def test_bench_eight_ranks_share_the_gpu_over_gloo():
     """the driver's N = 8 command line end to end at tiny size — rendezvous, one runtime set per rank, core slices, per-step
-    barrier + max over ranks, whole-job value, tear-down — with eight ranks on the one GPU of the test box (gloo; every process
-    keeps its own slabs for full score matrices, so they are made small here: eight processes share one device's memory)"""
-    env = dict(os.environ, PORESEQ_DIST_BACKEND="gloo", PORESEQ_SLAB_GB="1", PORESEQ_SLABS="1")
+    barrier + max over ranks, whole-job value, tear-down — with eight ranks on the one GPU of the test box (gloo).  Every rank
+    plans its slabs, shares and pool ceiling for an eighth of the device (dist.init -> PORESEQ_DEVICE_FRACTION, ps_info reports it)"""
+    env = dict(os.environ, PORESEQ_DIST_BACKEND="gloo")
+    for k in ("PORESEQ_SLAB_GB", "PORESEQ_SLABS", "PORESEQ_DEVICE_FRACTION"):
+        env.pop(k, None)
     out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
                                    "--master-addr", "127.0.0.1", "--master-port", "29523", os.path.join(B.ROOT, "bench.py"),
                                    "--gpus", "8", "--steps", "2", "--warmup", "0", "--length", "1000", "--regions-per-gpu", "4",
@@ -94,6 +96,7 @@ def test_bench_eight_ranks_share_the_gpu_over_gloo():
     assert r["n_gpus"] == 8 and r["scaling"] == "weak" and r["steps"] == 2 and r["value"] > 0
     assert abs(r["value"] - 8 * 4 * 1.0 * 2 / (2 * r["ms_per_step"] / 1e3)) < 1e-6 * r["value"]   # all ranks' regions over the sum of the steps' slowest-rank times
     assert len(r["batch_done_s"]) == 2 and "runtimes" in r["library"]
+    assert "device fraction of this process 0.125" in r["library"]
 
 
 @pytest.mark.gpu

@@ -1,0 +1,71 @@
+"""The bench's operating regime pinned to the REFERENCE at BASELINE config #2's size (VERDICT r4 "next" 2).
+
+bench.py's 200 kb/s come from several host threads inside the library at once, each driving a lock-step batch of 10 kb regions
+with the default kernel choice — which, with more than one thread in the library, is: strip sweeps with kept columns for every
+`ScoreMutations` launch size (two wavefronts per sweep), Smith-Waterman's packed 8-column fill, full matrices in the process-wide
+slabs for Refine.  Each piece is parity-tested on its own; here the combination replays the reference's own runs: four slots
+(poreseq_amd.dist.stream_batches), each a lock-step RegionBatch of three 10 kb / 10-event regions of which one is the
+`consensus_L10000_E10` fixture (the reference's 1 090 s schedule: per-call nbases, the sequence after every call, final ref_align /
+ref_like digests, final ScoreEvents) and, in one batch, another is `mutate_seeds_L10000` (one Mutate(list of seeds) call).
+Reference: poreseq/Mutate.py:62-93 through pyx:378-472."""
+import copy
+
+import numpy as np
+import pytest
+
+import backends as B
+import golden_util as G
+from poreseq_amd import _capi, synth
+from poreseq_amd import dist as psdist
+from poreseq_amd.batch import RegionBatch
+from poreseq_amd.poreseqcpp import PSAlign, swalign
+from test_golden_large import _final_refs
+
+
+@pytest.mark.gpu
+def test_four_slots_of_lock_step_10kb_batches_replay_the_reference_fixtures():
+    api = _capi.load_hip()
+    zc, zs = G.load("consensus_L10000_E10"), G.load("mutate_seeds_L10000")
+    fc, fs = G.regen(zc, swalign), G.regen(zs, swalign)              # (draft, events, truth, params), inputs verified by checksum
+    par = fc[3]
+    others = [synth.make_region(10000, 10, 7100 + k, swalign, par) for k in range(2)]
+    seeds = [str(s) for s in zs["seeds"]]
+
+    def region(src):
+        return B.make_pa(PSAlign, src[0], copy.deepcopy(src[1]), dict(par))
+
+    def work(slot):
+        api.prof_enable(2); api.prof_reset()                          # this thread's runtime: which kernels ran
+        srcs = [fc, fs, others[0]] if slot == 0 else [fc, others[slot % 2], others[(slot + 1) % 2]]
+        pas = [region(s) for s in srcs]
+        with RegionBatch(pas) as rb:
+            if slot == 0:                                             # one Mutate(list of seed strings, reps=2) call on the seed-list fixture
+                nb = rb.Mutate(idx=[1], seqs=seeds, reps=2)
+                assert nb[1] == int(zs["nbases"]) and pas[1].sequence == str(zs["sequence"])
+                rb.sync([1])
+                _final_refs(pas[1], zs, "mutate_seeds_L10000 (slot 0)")
+                assert np.array_equal(np.array(rb.ScoreEvents(idx=[1])[0]), zs["final_ScoreEvents"])
+            for call, nb, seq in zip(zc["calls"], zc["nbases"], zc["sequences"]):
+                call = str(call)
+                got = rb.Mutate(reps=4) if call == "Mutate:self" else rb.Mutate(seqs="viterbi") if call == "Mutate:viterbi" else rb.Refine()
+                assert got[0] == int(nb), (slot, call, got)
+                assert pas[0].sequence == str(seq), (slot, call)
+            rb.sync()
+            _final_refs(pas[0], zc, "consensus_L10000_E10 (slot %d)" % slot)
+            assert np.array_equal(np.array(rb.ScoreEvents(idx=[0])[0]), zc["final_ScoreEvents"])
+        ran = {k: api.prof_get(k)[1] for k in ("sweep", "sweep_w2", "sweep_w4", "fill", "sw", "sw_pk8", "slab")}
+        api.prof_enable(0)
+        return ran
+
+    for k in ("set_sweep_min", "set_sweep2_min", "set_sparse_min"):    # the library's own thresholds
+        getattr(api, k)(-1)
+    api.set_sweep_form(0, 0)
+    ran = psdist.stream_batches(range(4), work, in_flight=4, enter=psdist._enter_hip_library)
+    for slot, r in enumerate(ran):
+        # every ScoreMutations of the schedule but Refine's took the kept-column strip sweeps, two wavefronts each, whatever the launch
+        # size (with a lone thread they would start at 160 sweeps and a 3-region call's 60 would take k_fill); Refine's full matrices
+        # took a slab; every Smith-Waterman batch ran the packed 8-column fill
+        assert r["sweep"] > 0 and r["sweep_w2"] == r["sweep"] and r["sweep_w4"] == 0, (slot, r)
+        assert r["slab"] >= 4 and r["fill"] >= r["slab"], (slot, r)
+        assert r["sw"] > 0 and r["sw_pk8"] == r["sw"], (slot, r)
+    assert "slabs for full score matrices: 0 of" not in api.info()

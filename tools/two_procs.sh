@@ -1,0 +1,11 @@
+export PORESEQ_DEVICE_FRACTION=0.5
+(timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu --no-extras --regions-per-gpu 140 --batches-in-flight 7 > gpurun_out/two_a.json 2>/dev/null &)
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu --no-extras --regions-per-gpu 140 --batches-in-flight 7 > gpurun_out/two_b.json 2>/dev/null
+sleep 20
+python - <<'PY'
+import json
+for f in ("gpurun_out/two_a.json","gpurun_out/two_b.json"):
+    try:
+        d=[json.loads(l) for l in open(f) if l.startswith("{")][-1]; print(f, d["value"], d["ms_per_step"])
+    except Exception as e: print(f, "failed", e)
+PY
