@@ -38,7 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_OF = {"fill": "k_fill", "sweep": "k_sweep", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}   # "sweep" = k_sweep (forward-only), k_sweeps (kept columns), k_sweep2 (full records)
+KERNEL_OF = {"fill": "k_fill", "sweep": "k_sweep", "score": "k_score", "sw": "k_sw_fill", "viterbi": "k_vit_steps"}   # "sweep" = the strip-sweep class: k_sweeps(_w) (kept columns), k_sweep(_w) (forward-only), k_sweep2(_w) (full records); _w = two / four wavefronts per sweep
+SIMDS, FP64_LANES_PER_CLK, SHADER_GHZ = 1024, 16, 2.4          # MI355X: 256 CUs x 4 SIMDs, 16 FP64 lanes per SIMD and clock (78.6 TFLOP/s with FMA)
+FP64_OPS_PER_CELL = 45                                          # the reference's arithmetic per DP cell: emission 29 (AlignUtil.h:34-53), recurrence 16 (Alignment.cpp:196-267)
 
 
 def _cpu_region_worker(job):
@@ -233,6 +235,7 @@ def main():
         if timed:
             def collect():
                 p = {c: list(api.prof_get(c)) + [api.prof_units(c)] for c in KERNEL_OF}
+                p["_forms"] = [api.prof_get(c)[1] for c in ("sweep_w2", "sweep_w4", "sweep_kept")]   # host-side launch counts by form
                 api.prof_enable(0)
                 with plock:
                     profs.append(p)
@@ -240,6 +243,7 @@ def main():
             batch_done_s.append(sorted(round(it["done"], 3) for it in items))
             load_s.append(sum(it["load"] for it in items) / NB)
             live_prof.append({c: [sum(p[c][i] for p in profs) for i in range(4)] for c in KERNEL_OF})
+            live_prof[-1]["_forms"] = [sum(p["_forms"][i] for p in profs) for i in range(3)]
         outs = []
         for si, regs in enumerate(step_regs):
             out = [None] * len(regs)
@@ -278,6 +282,30 @@ def main():
         pre["north_star_1kb"] = {"region_bases": 1000, "events": args.events, "single_region_s": t1,
                                  "single_region_kb_s": 1.0 / t1, "lock_step_regions": len(k1),
                                  "lock_step_kb_s": len(k1) * 1.0 / tb}
+
+        # ---- BASELINE config #3's unit of work (poreseq variant, Variant.py:66-95: one ScoreMutations per region): one 10 kb region of
+        #      the 48 kb reference, 30 events, its share of the 10 000 point edits (1:3:4 del / sub / ins at uniform positions),
+        #      scoring_width 100 — the dense edit-scoring kernel's own figure ----
+        def variant3():
+            import numpy as np
+            from poreseq_amd.consensus import variant_region
+            vp = dict(params, scoring_width=100.0)
+            d, ev, tr = synth.make_region(10000, 30, 3003, swalign, vp, draft_error=0.0)
+            muts = synth.random_point_mutations(np.random.default_rng(3), d, 10000 // 6)
+            pa = PSAlign(); pa.sequence, pa.events, pa.params = d, ev, dict(vp)
+            variant_region(pa, copy.deepcopy(muts))                   # warm: pools, code objects
+            api.prof_reset(); api.prof_enable(1)
+            t = time.perf_counter(); variant_region(pa, copy.deepcopy(muts)); wall = time.perf_counter() - t
+            api.prof_enable(0)
+            ms, n, nb = api.prof_get("score")
+            items = api.prof_units("score")
+            return {"region_bases": 10000, "events": len(ev), "edits": len(muts), "scoring_width": 100, "call_s": wall, "items": items,
+                    "items_per_s_call": items / wall, "k_score_ms": ms, "k_score_launches": int(n), "items_per_s_kernel": items / (ms / 1e3) if ms > 0 else None,
+                    "alg_bytes_per_item": nb / items if items else None, "achieved_gbs": (nb / 1e9) / (ms / 1e3) if ms > 0 else None,
+                    "frac_of_hbm_peak": (nb / 1e9) / (ms / 1e3) / HBM_PEAK_GBS if ms > 0 else None,
+                    "note": "k_score (+ k_old): SURVEY 8(d) bytes per (event, edit) item, 16(Bs+1) + 16 Br + 24(Bs+c) + 32 Br/k + 8 with Bs = 201, Br = 601 "
+                            "(37.1 KB for edits at distinct positions); call_s also holds the forward + backward fills and the backtrace of the 30 events"}
+        pre["variant_config3"] = in_slot(variant3)
 
     start_slots(NB)
     on_every_slot(api.prof_reset)     # every slot owns its runtime before the first batch sizes its pools: the device is shared NB ways from the start
@@ -344,7 +372,15 @@ def main():
             dom = max(tot, key=lambda c: tot[c][0])
             ms, launches, nbytes, units = tot[dom]
             achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            kname, kclass = KERNEL_OF[dom], None
+            if dom == "sweep":
+                # the class's dominant kernel: kept-column sweeps of ScoreMutations (k_sweeps) or forward-only sweeps (k_sweep), one wavefront
+                # per sweep or two / four (_w); by launch counts the library keeps per form
+                w2, w4, kept = (sum(lp["_forms"][i] for lp in live_prof) for i in range(3))
+                kname = ("k_sweeps" if 2 * kept >= launches else "k_sweep") + ("_w" if 2 * (w2 + w4) >= launches else "")
+                kclass = {"name": "strip sweeps: k_sweeps(_w) kept columns, k_sweep(_w) forward-only", "launches": int(launches), "kept_column_launches": int(kept),
+                          "two_wavefronts_per_sweep": int(w2), "four_wavefronts_per_sweep": int(w4), "one_wavefront_per_sweep": int(launches - w2 - w4)}
+            roof = {"bound": "hbm", "kernel": kname, "class": kclass, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": int(launches),
                     "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": nbytes / max(launches, 1),
                     "sweeps_per_launch": units / max(launches, 1) if dom in ("fill", "sweep") else None,
@@ -421,6 +457,15 @@ def main():
                     roof["valu"] = {"source": rel + " ignored: measured on a different launch shape"}
             except (OSError, ValueError, KeyError, ZeroDivisionError, IndexError):
                 pass
+            # what the DP fills are short of is FP64 vector issue, not bytes: useful FP64 operations of the reference's arithmetic (45 per band
+            # cell, every sweep of both fill classes) over the wall time, against the chip's non-FMA FP64 issue peak
+            band = min(2.0 * float(params.get("realign_width", 300)) + 1.0, 0.95 * args.length)
+            cells = (tot["fill"][3] + tot["sweep"][3]) * (args.length - 4) * band
+            peak_ops = SIMDS * FP64_LANES_PER_CLK * SHADER_GHZ * 1e9
+            roof["fp64"] = {"useful_ops_per_s": cells * FP64_OPS_PER_CELL / dt if dt > 0 else None, "peak_ops_per_s": peak_ops,
+                            "frac": cells * FP64_OPS_PER_CELL / dt / peak_ops if dt > 0 else None, "band_cells_per_step": cells / max(args.steps, 1),
+                            "note": "DP fills only (edit scoring, Smith-Waterman and Viterbi do other work on the same pipes); peak = %d SIMDs x %d FP64 lanes "
+                                    "x %.1f GHz, one operation per lane and clock (no FMA: the reference's arithmetic is not fused)" % (SIMDS, FP64_LANES_PER_CLK, SHADER_GHZ)}
             out["roofline"] = roof
             sched = {"fill_sweeps": (tot["fill"][3] + tot["sweep"][3]) / max(args.steps, 1), "score_items": tot["score"][3] / max(args.steps, 1)}
 

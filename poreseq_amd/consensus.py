@@ -205,7 +205,7 @@ def merge_seqs(seq1, seq2, overlap=1000, swalign=None):
     return seq1[:tail_from + a_mid] + seq2[b_mid:]
 
 
-def polish(sequence, make_region_pa, params=None, region_length=10000, overlap=1000, batch=16, reps=4, refine=None):
+def polish(sequence, make_region_pa, params=None, region_length=10000, overlap=1000, batch=16, reps=4, refine=None, swalign=None):
     """Assembly polish = the reference's split -> consensus per region -> merge pipeline (split_fasta.py:50-133,
     `poreseq consensus` per region file, merge_fasta.py:41-80) as one call.
 
@@ -214,6 +214,7 @@ def polish(sequence, make_region_pa, params=None, region_length=10000, overlap=1
                      (what LoadAlignedEvents returns for region 'start:end')
     batch            regions refined in lock-step per GPU (poreseq_amd.batch); `refine` replaces the default
                      `poreseq_amd.dist.refine_regions` (regions sharded over the ranks of the process group, longest first)
+    swalign          the Smith-Waterman the stitching uses (default: this package's, on the GPU; tests of the driver pass a checker's)
     Returns (polished sequence, [(start, end, region consensus, accuracy)]).  With an `end_trim` in `params` the region
     sequences lose that many bases per end before stitching, exactly as the region FASTA files of the reference do.
     """
@@ -223,5 +224,5 @@ def polish(sequence, make_region_pa, params=None, region_length=10000, overlap=1
     done = refine(regs, make_region_pa, params=params, batch=batch, reps=reps)
     merged = done[0][0]
     for seq, _ in done[1:]:
-        merged = merge_seqs(merged, seq, overlap)
+        merged = merge_seqs(merged, seq, overlap, swalign)
     return merged, [(a, b, s, acc) for (a, b), (s, acc) in zip(regs, done)]

@@ -433,7 +433,10 @@ int sweep_run(Runtime* rt, Batch& bt) {
     }
     PS_LAUNCH_CHECK();
     prof_end(rt, "sweep", 0.0);
-    if (rt->prof_on && NW > 1) rt->prof[NW == 2 ? "sweep_w2" : "sweep_w4"].launches++;   // (which form ran: a host-side count, no event pair)
+    if (rt->prof_on) {   // (which form ran: host-side counts, no event pair)
+        if (NW > 1) rt->prof[NW == 2 ? "sweep_w2" : "sweep_w4"].launches++;
+        if (bt.ndir == 2 && bt.sparse) rt->prof["sweep_kept"].launches++;
+    }
     hipLaunchKernelGGL(k_best, dim3(b.njobs), dim3(64), 0, rt->stream, b, sw);
     if (bt.ndir == 2) PS_TRY(launch_prefix(rt, b, 2));   // running MaxInfo per column of both directions (the strip jobs' best cell is k_best's)
     switch (K) {

@@ -245,6 +245,14 @@ def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_e
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     mine = shard(regions, rank, world, weights=[b - a for a, b in regions])
+    if world > len(regions) and rank == 0:
+        # fewer region work-items than ranks (BASELINE config #4: 6 regions of a 48.5 kb genome on 8 GPUs): the path shards by region
+        # (cmdline.py:182-195), so the ranks beyond the regions have nothing to refine and only take part in the final gather.  A
+        # `variant`-type call (one ScoreMutations per region) can use them: score_mutations_event_sharded deals a region's EVENTS.
+        import sys
+        busy = sorted({r for r in range(world) if shard(regions, r, world, weights=[b - a for a, b in regions])})
+        sys.stderr.write("[poreseq_amd.dist] %d regions on %d ranks: ranks %s idle during the refinement (the schedule shards by region)\n"
+                         % (len(regions), world, [r for r in range(world) if r not in busy]))
     hip_backend = False   # (decided on the first region's object: a driver over a CPU checker must not start HIP runtimes)
     step = max(1, int(batch))
     chunks = [mine[k:k + step] for k in range(0, len(mine), step)]

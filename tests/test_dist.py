@@ -119,6 +119,56 @@ def test_refine_regions_uneven_world2_equals_world1():
     assert one["maxload"] == 900 and two["maxload"] <= 450 + 270
 
 
+WORKER_POLISH = r'''
+import copy, os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import backends as B
+from poreseq_amd import consensus, dist as psdist, synth
+from poreseq_amd.util import DEFAULT_PARAMS
+rank, local, world = psdist.init(backend="gloo")
+P = dict(DEFAULT_PARAMS, verbose=0)
+P.pop("end_trim")
+rng = np.random.default_rng(44)
+truth = synth.random_sequence(rng, 1750)              # six overlapping region work-items, the last ones short (split_fasta.py:94-101 steps by length - 1000)
+made = []
+def make(a, b):
+    made.append((a, b))
+    d, events, _ = synth.make_region(b - a, 3, 900 + a, B.oracle_swalign, P, truth=truth[a:b], draft_error=0.01)
+    return B.make_pa(B.OraclePSAlign, d, events, P)
+seq, parts = consensus.polish(truth, make, params=None, region_length=1300, batch=2, reps=1, swalign=B.oracle_swalign)
+loads = [None] * world
+import torch.distributed as dist
+if dist.is_initialized():
+    dist.all_gather_object(loads, made)
+else:
+    loads = [made]
+if rank == 0:
+    print(json.dumps({"world": world, "seq": seq, "regions": [[a, b] for a, b, _, _ in parts], "accs": [p[3] for p in parts], "made": loads}))
+'''
+
+
+def test_polish_six_regions_on_eight_ranks_equals_one_rank():
+    """BASELINE config #4's shape (6 region work-items, 8 ranks) through the package-level driver split -> refine -> merge: the six
+    regions go to six ranks, two ranks refine nothing and only take part in the final gather (the log says which), and every rank
+    ends with the same stitched sequence as a single rank computes.  Reference: split_fasta.py:94-101, cmdline.py:182-195, merge_fasta.py:8-39."""
+    global WORKER
+    keep, WORKER = WORKER, WORKER_POLISH
+    try:
+        one = run_world(1)
+        code = WORKER % {"root": ROOT}
+        out = _torchrun(code, 8, 29500 + (os.getpid() * 11 + 977) % 2000).decode()
+    finally:
+        WORKER = keep
+    import json
+    eight = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert eight["world"] == 8 and eight["regions"] == [[0, 1300], [300, 1600], [600, 1750], [900, 1750], [1200, 1750], [1500, 1750]]
+    assert eight["seq"] == one["seq"] and eight["accs"] == one["accs"]
+    assert sorted(len(m) for m in eight["made"]) == [0, 0, 1, 1, 1, 1, 1, 1]              # one region per rank, two ranks idle
+    assert sorted(tuple(r) for m in eight["made"] for r in m) == [tuple(r) for r in sorted(eight["regions"])]   # every region built once
+    assert "6 regions on 8 ranks: ranks [6, 7] idle" in out
+
+
 def test_split_and_merge_regions():
     assert consensus.split_regions(35000, 10000) == [(0, 10000), (9000, 19000), (18000, 28000), (27000, 35000)]
     assert consensus.split_regions(8000, 10000) == [(0, 8000)]

@@ -69,3 +69,40 @@ def test_four_slots_of_lock_step_10kb_batches_replay_the_reference_fixtures():
         assert r["slab"] >= 4 and r["fill"] >= r["slab"], (slot, r)
         assert r["sw"] > 0 and r["sw_pk8"] == r["sw"], (slot, r)
     assert "slabs for full score matrices: 0 of" not in api.info()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw", [1, 2, 4])
+def test_first_call_of_a_fresh_process_is_a_kept_column_sweep(nw):
+    """A process whose FIRST device work is a column-sparse ScoreMutations with edits at both ends of the sequence (kept column 0 and
+    the last one): the record and code pools are then exactly as large as this call needs, so a store outside them is a memory fault
+    instead of a silent write into a pool another test had grown (the kept columns' padding once wrapped an unsigned offset that way).
+    Scores and alignments equal the oracle's."""
+    import os, subprocess, sys
+    code = (
+        "import sys, copy; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, backends as B\n"
+        "from poreseq_amd import synth, _capi\n"
+        "from poreseq_amd.poreseqcpp import PSAlign\n"
+        "from poreseq_amd.util import DEFAULT_PARAMS, MutationInfo\n"
+        "P = dict(DEFAULT_PARAMS, verbose=0)\n"
+        "draft, events, truth = synth.make_region(1500, 5, 9100, B.oracle_swalign, P)\n"
+        "def e(st, o, m):\n"
+        "    x = MutationInfo(); x.start, x.orig, x.mut = st, o, m; return x\n"
+        "n = len(draft)\n"
+        "muts = [e(0, '', 'T'), e(0, draft[0], ''), e(1, draft[1], 'G'), e(2, '', 'AC'), e(n - 1, draft[n - 1], 'A'), e(n - 2, '', 'G'), e(n, '', 'A'),\n"
+        "        e(n // 2, draft[n // 2], ''), e(n // 3, '', 'T')]\n"
+        "api = _capi.load_hip(); api.set_sparse_min(0); api.set_sweep_form(0, %d)\n"
+        "api.prof_enable(1)\n"
+        "res = []\n"
+        "for cls in (PSAlign, B.OraclePSAlign):\n"
+        "    pa = B.make_pa(cls, draft, copy.deepcopy(events), P)\n"
+        "    got = pa.ScoreMutations(muts)\n"
+        "    res.append(([g.score for g in got], [ev.ref_align.copy() for ev in pa.events], [ev.ref_like.copy() for ev in pa.events]))\n"
+        "assert api.prof_get('sweep')[1] == 1 and api.prof_get('fill')[1] == 0\n"
+        "assert res[0][0] == res[1][0]\n"
+        "assert all(np.array_equal(a, b) for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]))\n"
+        "print('FRESH-OK')\n"
+    ) % (B.ROOT, os.path.join(B.ROOT, "tests"), nw)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FRESH-OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
