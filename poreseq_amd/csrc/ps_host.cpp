@@ -1017,19 +1017,21 @@ struct ParPool {
         cv.notify_all();
     }
 };
-ParPool* par_pool() { static ParPool* p = new ParPool(); return p; }   // (never destroyed: its threads are detached and may outlive main)
+static int par_cap() { static const int cap = [] { const char* e = getenv("PORESEQ_HOST_THREADS"); const int v = e ? atoi(e) : 32; return std::max(1, std::min(v, 64)); }(); return cap; }
+ParPool* par_pool() {   // (never destroyed: its threads are detached and may outlive main; its size is set once, here)
+    static ParPool* p = [] { ParPool* q = new ParPool(); q->cap = (size_t)std::max(2 * par_cap(), 8); return q; }();
+    return p;
+}
 }  // namespace
 
 void par_for(int n, const std::function<void(int)>& fn) {
     if (n <= 1) { if (n == 1) fn(0); return; }
-    static const int cap = [] { const char* e = getenv("PORESEQ_HOST_THREADS"); const int v = e ? atoi(e) : 32; return std::max(1, std::min(v, 64)); }();
+    const int cap = par_cap();
     const int nth = std::min(n, cap);
     if (nth <= 1) { for (int k = 0; k < n; k++) fn(k); return; }
     std::shared_ptr<ParJob> j = std::make_shared<ParJob>();
     j->fn = fn; j->n = n;
-    ParPool* pool = par_pool();
-    pool->cap = (size_t)std::max(2 * cap, 8);
-    pool->submit(j, nth - 1);
+    par_pool()->submit(j, nth - 1);
     j->run();
     std::unique_lock<std::mutex> lk(j->mu);
     j->cv.wait(lk, [&] { return j->done.load() >= n; });

@@ -3,22 +3,25 @@
 #   plain run (the bench line the counters are compared with), FETCH_SIZE pass, WRITE_SIZE pass (separate passes, kernel-trace only, as
 #   the pool requires), one pass with the SQ counters of vector issue.
 # usage on the GPU box: bash tools/pmc_round.sh <tag>   -> gpurun_out/prof/<tag>_traffic.json, <tag>_valu.json, <tag>_bench_line.json
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it)}"
 cd /tmp && export TMPDIR=/tmp
-TAG=${1:-r04}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof; mkdir -p $OUT
-python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu > /tmp/pmcr_plain.log 2>&1
+TAG=${1:-r05}
+OUT="$GRAFT_REPO_ROOT/gpurun_out/prof"; mkdir -p "$OUT"
+python3 "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu > /tmp/pmcr_plain.log 2>&1
+grep -q '^{' /tmp/pmcr_plain.log || { echo "pmc_round: the plain bench run printed no JSON line" >&2; tail -5 /tmp/pmcr_plain.log >&2; exit 1; }
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmcr_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcr_$c -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-extras > /tmp/pmcr_$c.log 2>&1
+  rm -rf "/tmp/pmcr_$c"
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "/tmp/pmcr_$c" -o r -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --no-cpu --no-extras > "/tmp/pmcr_$c.log" 2>&1
 done
 rm -rf /tmp/pmcr_valu
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d /tmp/pmcr_valu -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-extras > /tmp/pmcr_valu.log 2>&1
-python3 - $OUT/${TAG} <<'PY'
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d /tmp/pmcr_valu -o r -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu --no-extras > /tmp/pmcr_valu.log 2>&1
+python3 - "$OUT/${TAG}" <<'PY'
 import csv, glob, json, sys, collections
 pre = sys.argv[1]
 plain = [json.loads(l) for l in open("/tmp/pmcr_plain.log") if l.startswith("{")][-1]
 cfg = plain["config"]
-short = lambda n: n.split("(")[0].replace("void ", "").replace("ps::", "").split("<")[0]
+short = lambda n: n.split("(")[0].replace("void ", "").replace("ps::", "").split("<")[0]   # (k_sweeps_w<4, 2> -> k_sweeps_w)
 # ---- traffic
 tot = {}; n = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -35,7 +38,7 @@ for name in sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]), key=lambda x
                   "write_bytes_per_launch": tot["WRITE_SIZE"][name] / max(n["WRITE_SIZE"][name], 1), "launches": max(n["FETCH_SIZE"][name], n["WRITE_SIZE"][name], 1),
                   "fetch_gb": tot["FETCH_SIZE"][name] / 1e9, "write_gb": tot["WRITE_SIZE"][name] / 1e9}
 # the profile class "sweep" of bench.py covers k_sweep (forward-only), k_sweeps (kept columns) and k_sweep2 (full records): one entry for the class
-cls = {"k_sweep": ("k_sweep", "k_sweeps", "k_sweep2"), "k_fill": ("k_fill", "k_fill_wide")}
+cls = {"k_sweep": ("k_sweep", "k_sweeps", "k_sweep2", "k_sweep_w", "k_sweeps_w", "k_sweep2_w"), "k_fill": ("k_fill", "k_fill_wide")}
 for cname, members in cls.items():
     fb = sum(tot["FETCH_SIZE"][m] for m in members); wb = sum(tot["WRITE_SIZE"][m] for m in members)
     L = sum(max(n["FETCH_SIZE"][m], n["WRITE_SIZE"][m]) for m in members)
@@ -43,8 +46,9 @@ for cname, members in cls.items():
         kern["class:" + cname] = {"members": [m for m in members if n["FETCH_SIZE"][m] or n["WRITE_SIZE"][m]], "launches": L,
                                   "fetch_bytes_per_launch": fb / L, "write_bytes_per_launch": wb / L, "fetch_gb": fb / 1e9, "write_gb": wb / 1e9}
 roof = plain.get("roofline", {})
-if "class:" + roof.get("kernel", "") in kern:
-    kern["class:" + roof["kernel"]]["alg_bytes_per_launch"] = roof["alg_bytes_per_launch"]
+rk = "class:k_sweep" if roof.get("kernel", "").startswith("k_sweep") else "class:" + roof.get("kernel", "")
+if rk in kern:
+    kern[rk]["alg_bytes_per_launch"] = roof["alg_bytes_per_launch"]
 allb = sum(tot["FETCH_SIZE"].values()) + sum(tot["WRITE_SIZE"].values())
 shape = {"length": cfg["region_bases"], "events": cfg["events"], "regions_per_gpu": cfg["regions_per_gpu"], "batches_in_flight": cfg["batches_in_flight"],
          "regions_per_batch": max(1, cfg["regions_per_gpu"] // cfg["batches_in_flight"])}
@@ -69,8 +73,14 @@ for r in csv.DictReader(open(f)):
 busy = sum(v["SQ_ACTIVE_INST_VALU"] for v in t.values())
 W = 2 * 300 + 1
 cells = float(cfg["region_bases"] - 4) * W                      # band cells of one 10 kb sweep at realign_width 300
+import re
 sweepk = [k for k in t if k.startswith("k_sweep")]
-sw_inst = sum(t[k]["SQ_INSTS_VALU"] for k in sweepk); sw_waves = sum(t[k]["SQ_WAVES"] for k in sweepk)
+def form(k):   # rows per lane, wavefronts per sweep: k_sweeps<10, true> / k_sweeps_w<4, 2>
+    m = re.match(r"k_sweep\w*<(\d+), (\w+)>", k)
+    return (int(m.group(1)), int(m.group(2)) if m.group(2).isdigit() else 1) if m else (10, 1)
+sw_inst = sum(t[k]["SQ_INSTS_VALU"] for k in sweepk)
+sw_waves = sum(t[k]["SQ_WAVES"] / form(k)[1] for k in sweepk)                                   # sweeps, not wavefronts
+lane_cells = sum(t[k]["SQ_WAVES"] * (cfg["region_bases"] - 4 + 0.95 * cfg["region_bases"] / form(k)[0]) * form(k)[0] for k in sweepk)   # steps x rows per lane, per wavefront
 step_s = plain["ms_per_step"] / 1e3
 valu = dict(shape)
 valu.update({"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extras; tools/pmc_round.sh",
@@ -80,7 +90,8 @@ valu.update({"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_I
              "busy_frac": busy * 4 / 1024 / 2.4e9 / step_s,
              "sweep_kernels": {"wave_insts_per_sweep": sw_inst / max(sw_waves, 1), "sweeps": sw_waves,
                                "lane_insts_per_band_cell": 64.0 * sw_inst / max(sw_waves, 1) / cells,
-                               "insts_per_lane_cell": sw_inst / max(sw_waves, 1) / ((cfg["region_bases"] - 4 + 1100) * 10.0),
+                               "insts_per_lane_cell": sw_inst / max(lane_cells, 1),
+                               "forms": {k: {"rows_per_lane": form(k)[0], "wavefronts_per_sweep": form(k)[1], "sweeps": t[k]["SQ_WAVES"] / form(k)[1]} for k in sweepk},
                                "fp64_ops_per_cell_reference_arithmetic": 45},
              "by_kernel": {k: {"launches": nl[k], "valu_insts_g": v["SQ_INSTS_VALU"] / 1e9, "valu_busy_share": v["SQ_ACTIVE_INST_VALU"] / busy, "waves_m": v["SQ_WAVES"] / 1e6}
                            for k, v in sorted(t.items(), key=lambda kv: -kv[1]["SQ_ACTIVE_INST_VALU"])[:16]}})
@@ -90,4 +101,4 @@ print("VALU busy: %.2f s of all SIMDs at 2.4 GHz over a %.2f s step = %.2f; swee
 for k, v in list(valu["by_kernel"].items())[:10]:
     print("  %-34s %6d launches %9.2f G insts  %5.1f %%" % (k[:34], v["launches"], v["valu_insts_g"], 100 * v["valu_busy_share"]))
 PY
-grep '^{' /tmp/pmcr_plain.log | tail -1 > $OUT/${TAG}_bench_line.json
+grep '^{' /tmp/pmcr_plain.log | tail -1 > "$OUT/${TAG}_bench_line.json"

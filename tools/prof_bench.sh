@@ -37,7 +37,7 @@ print("timed step %.0f ms: %d kernels, sum of durations %.0f ms, no kernel in fl
 for n, v in tot.most_common(12): print("  %-26s %5d launches %9.1f ms  avg %8.1f us" % (n[:26], cnt[n], v / 1e6, v / cnt[n] / 1e3))
 h = collections.defaultdict(lambda: [0, 0])
 for s, e, n, g in rows:
-    if n.startswith("k_fill<") or n.startswith("k_sweep<"):
+    if n.startswith("k_fill<") or n.startswith("k_sweep"):
         b = 1
         while b < g: b *= 2
         h[b][0] += 1; h[b][1] += e - s
