@@ -291,7 +291,7 @@ int likes_max_states() { return LK_MAXC - 4; }
 #define PS_LAUNCH_CHECK() PS_HIP(hipGetLastError())
 
 // Forms of the strip sweep: K rows per lane on NW wavefronts per sweep (NL = 64 NW lanes).  The strips in band on one step form a
-// window of about (2W + 1) / (K + levels per base) + 2 strips, which must fit NL - 2 lanes.
+// window of about (2W + 1) / (K + levels per base) + 2 strips, which must fit NL - 1 lanes (sweep_win_max).
 //   NW = 1   one wavefront per sweep: the fewest instructions per cell at K = 10 for the default width (57 of 64 lanes busy), ~27 ms
 //            for a 10 kb sweep whatever the chip could do
 //   NW = 2   K = 4: the same SIMD time per sweep (120 of 128 lanes busy; the per-step overhead of a lane is spread over 4 cells
@@ -301,7 +301,12 @@ static const int K_LIST1[] = {4, 6, 10, 16, 24, 32, 0};
 static const int K_LIST2[] = {4, 5, 6, 10, 0};
 static const int K_LIST4[] = {2, 3, 4, 6, 0};
 static const int* k_list(int NW) { return NW == 1 ? K_LIST1 : NW == 2 ? K_LIST2 : NW == 4 ? K_LIST4 : nullptr; }
-int sweep_win_max(int NW) { return 64 * NW - 2; }
+// The strips in band on one step must leave ONE lane of the sweep idle: the lane above the lowest strip in band then holds a strip
+// that is out of band, so what the first row of a band reads as its upper neighbour is the absent-cell value (a band's top row has no
+// neighbour above: cpp/Alignment.cpp:226-236; the kernels do not mask it, they rely on that value).  With a window of NL - 1 strips at
+// most, the strip NL above the one a lane has just left cannot be in band yet.  (Rounds 3-4 kept two lanes idle; the bench's windows
+// at K = 4 sit at 125-128 strips of 128 lanes, and every window of 127 took the next larger strip height at +16 % instructions.)
+int sweep_win_max(int NW) { return 64 * NW - 1; }
 static int guess_window(int W, int K) { return (2 * W + 1) / (K + 1) + 3; }
 
 // smallest strip height on NW wavefronts whose window probably fits (K = 0: none)

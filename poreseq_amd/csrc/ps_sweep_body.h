@@ -25,7 +25,8 @@ __device__ __forceinline__ int code_off(int lane, int r, int nl) {
 
 struct StripBest { double v; int i, j; };
 constexpr int Q_PAD = 8;          // qlo entries behind T (all -1): the sweep looks three steps ahead
-// strips in band on one step: at most NL - 2, two lanes stay idle (a lane is never handed its next strip in the step it leaves one)
+// strips in band on one step: at most NL - 1, one lane stays idle (sweep_win_max, ps_sweep.hip: the lane above the lowest strip in band must hold
+// an out-of-band strip, whose cells are the absent-cell value the band's top row reads as its upper neighbour)
 
 __device__ __forceinline__ double wave_ror1(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -43,7 +44,7 @@ __device__ __forceinline__ double keep_or_absent(double x, bool keep) {
     return __hiloint2double(hi, __double2loint(x));
 }
 
-// columns of the LDS ring of per-column maxima: the widest window (NL - 2 strips) + the 64 steps between two flushes, rounded up
+// columns of the LDS ring of per-column maxima: the widest window (NL - 1 strips) + the 64 steps between two flushes, rounded up
 __host__ __device__ constexpr int ring_cols(int nw) { return nw <= 2 ? 256 : 512; }
 constexpr int HAND_DOUBLES = 4;   // LDS hand-off record of a wave's last lane: {main, stay (+ emission), main + emission, -}
 

@@ -57,9 +57,12 @@ void k_sweeps_w(BatchD b, SweepD sw) {
 
 template <int K, int NW>
 static void launch_w(Runtime* rt, const BatchD& b, const SweepD& sw) {
-    if (sw.ndir == 2 && sw.sparse) hipLaunchKernelGGL((k_sweeps_w<K, NW>), dim3(b.njobs * 2), dim3(64 * NW), 0, rt->stream, b, sw);
-    else if (sw.ndir == 2) hipLaunchKernelGGL((k_sweep2_w<K, NW>), dim3(b.njobs * 2), dim3(64 * NW), 0, rt->stream, b, sw);
-    else hipLaunchKernelGGL((k_sweep_w<K, NW>), dim3(b.njobs), dim3(64 * NW), 0, rt->stream, b, sw);
+    // PORESEQ_SWEEP_LDS_PAD_KB (tuning): dynamic LDS a sweep's workgroup claims on top of its own, i.e. a cap on the sweeps resident per CU
+    // (160 KB of LDS per CU) that leaves registers and wave slots to the short kernels of the other batches' chains
+    static const size_t pad = getenv("PORESEQ_SWEEP_LDS_PAD_KB") ? (size_t)atoi(getenv("PORESEQ_SWEEP_LDS_PAD_KB")) * 1024 : 0;
+    if (sw.ndir == 2 && sw.sparse) hipLaunchKernelGGL((k_sweeps_w<K, NW>), dim3(b.njobs * 2), dim3(64 * NW), pad, rt->stream, b, sw);
+    else if (sw.ndir == 2) hipLaunchKernelGGL((k_sweep2_w<K, NW>), dim3(b.njobs * 2), dim3(64 * NW), pad, rt->stream, b, sw);
+    else hipLaunchKernelGGL((k_sweep_w<K, NW>), dim3(b.njobs), dim3(64 * NW), pad, rt->stream, b, sw);
 }
 
 bool sweepw_launch(Runtime* rt, const BatchD& b, const SweepD& sw, int K, int NW) {

@@ -106,3 +106,42 @@ def test_first_call_of_a_fresh_process_is_a_kept_column_sweep(nw):
     ) % (B.ROOT, os.path.join(B.ROOT, "tests"), nw)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FRESH-OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.gpu
+def test_windows_that_leave_one_lane_idle_match_the_oracle():
+    """A strip sweep's window (strips in band on one step) may take all lanes of the sweep but one (sweep_win_max: the lane above the lowest
+    strip in band must hold an out-of-band strip).  Band widths scanned around the point where the window of K = 4 rows per lane reaches 63 of
+    64 lanes (one wavefront) and 127 of 128 (two): forward and backward DP matrices with step codes (ps_debug_fill) and ScoreEvents equal
+    the oracle at every width, and the trace shows that the maximal windows were among them."""
+    import os, re, subprocess, sys
+    code = (
+        "import sys, copy; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, backends as B\n"
+        "from poreseq_amd import synth, _capi\n"
+        "from poreseq_amd.poreseqcpp import PSAlign\n"
+        "from poreseq_amd.util import DEFAULT_PARAMS\n"
+        "hip, orc = _capi.load_hip(), B.oracle_api()\n"
+        "hip.set_sweep_min(0); hip.set_sweep2_min(0); hip.set_sparse_min(0)\n"
+        "for nw, widths, L in ((1, range(144, 160), 900), (2, range(296, 312, 2), 1500)):\n"
+        "    hip.set_sweep_form(4, nw)\n"
+        "    for W in widths:\n"
+        "        P = dict(DEFAULT_PARAMS, verbose=0, realign_width=float(W))\n"
+        "        draft, events, truth = synth.make_region(L, 2, 6000 + W, B.oracle_swalign, P)\n"
+        "        mk = lambda cls: B.make_pa(cls, draft, copy.deepcopy(events), P)\n"
+        "        assert mk(PSAlign).ScoreEvents() == mk(B.OraclePSAlign).ScoreEvents(), (nw, W)\n"
+        "        for d in (0, 1):\n"
+        "            out = []\n"
+        "            for api in (hip, orc):\n"
+        "                h = api.align_create(draft, copy.deepcopy(events), P)\n"
+        "                out.append(api.debug_fill(h, 1, d, events[1].mean.size, len(draft) - 4))\n"
+        "                api.align_destroy(h)\n"
+        "            for k in range(4 if d == 0 else 2):\n"
+        "                assert np.array_equal(out[0][k], out[1][k], equal_nan=True), (nw, W, d, k)\n"
+        "print('WINDOWS-OK')\n"
+    ) % (B.ROOT, os.path.join(B.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, env=dict(os.environ, PORESEQ_TRACE="1"))
+    assert r.returncode == 0 and "WINDOWS-OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    wins = {(int(k), int(n), int(w)) for k, n, w in re.findall(r"K = (\d+) on (\d) wavefronts, widest window (\d+) strips", r.stderr)}
+    assert (4, 1, 63) in wins and (4, 2, 127) in wins, sorted(wins)            # the windows that use every lane but one did occur
+    assert any(k > 4 for k, n, w in wins)                                      # and wider ones took the next strip height
