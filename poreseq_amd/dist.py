@@ -196,6 +196,55 @@ def score_mutations_event_sharded(pa, muts, make_pa=None):
     return out
 
 
+def variant_regions(regions, make_region_pa, muts_of):
+    """`poreseq variant` (Variant.py:66-95: one ScoreMutations per region, starts absolute in the files and region-relative inside the call)
+    over the ranks of the process group.  regions: [(start, end)]; make_region_pa(start, end) -> PSAlign of the region; muts_of(start, end) ->
+    the MutationInfo list of the region with ABSOLUTE starts (not empty).
+
+    With at least as many regions as ranks the path shards by region, like everything else (longest first; one all_gather of the scores).
+    With FEWER regions than ranks — BASELINE config #3 / #4's six regions on eight GPUs — no rank idles: every region is scored by ALL ranks,
+    its events dealt to them (`score_mutations_event_sharded`: per-event terms all-gathered and added in the reference's event order,
+    bit-identical to the unsharded call).  Every rank returns [list of MutationScore] per region, starts absolute."""
+    from .consensus import variant_region
+    from .util import MutationScore
+    import copy as _copy
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lists = [muts_of(a, b) for a, b in regions]
+    if any(len(l) == 0 for l in lists):
+        raise ValueError("variant_regions: every region needs an explicit edit list (for all point edits call PSAlign.ScorePoints per region)")
+    if world > len(regions):
+        if rank == 0:
+            import sys
+            sys.stderr.write("[poreseq_amd.dist] %d regions on %d ranks: variant scoring shards each region's events over all ranks\n" % (len(regions), world))
+        out = []
+        for (a, b), muts in zip(regions, lists):
+            pa = make_region_pa(a, b)
+            rel = _copy.deepcopy(muts)
+            for m in rel:
+                m.start -= a
+            sc = score_mutations_event_sharded(pa, rel)
+            for m in sc:
+                m.start += a
+            out.append(sc)
+        return out
+    mine = shard(regions, rank, world, weights=[b - a for a, b in regions])
+    local = []
+    for idx, (a, b) in mine:
+        sc = variant_region(make_region_pa(a, b), _copy.deepcopy(lists[idx]), region_start=a)
+        local.append((idx, "", np.array([m.score for m in sc], dtype=np.float64)))
+    got = gather_regions(local, len(regions), max(len(l) for l in lists))
+    out = []
+    for (a, b), muts, (_, sc) in zip(regions, lists, got):
+        res = []
+        for m, v in zip(muts, sc[:len(muts)]):
+            ms = MutationScore()
+            ms.start, ms.orig, ms.mut, ms.score = m.start, m.orig, m.mut, float(v)
+            res.append(ms)
+        out.append(res)
+    return out
+
+
 def _fresh_region_rand():
     """Every region starts from the random stream of a fresh process — the reference runs one `poreseq consensus`
     process per region file and never seeds rand() (Viterbi.cpp:108) — whichever thread refines it."""

@@ -353,6 +353,54 @@ def test_event_sharded_scoring_equals_unsharded_world1_and_world2():
     assert one["n"] == two["n"] == 150 and one["npos"] == two["npos"] > 0
 
 
+WORKER_VARIANT = r'''
+import copy, os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import backends as B
+from poreseq_amd import dist as psdist, synth
+from poreseq_amd.consensus import variant_region
+from poreseq_amd.util import DEFAULT_PARAMS
+rank, local, world = psdist.init(backend="gloo")
+P = dict(DEFAULT_PARAMS, verbose=0)
+NREG = int(os.environ["NREG"])
+regions = [(1000 * k, 1000 * k + 220 + 30 * k) for k in range(NREG)]
+def make(a, b):
+    draft, events, truth = synth.make_region(b - a, 5, 700 + a, B.oracle_swalign, P)
+    return B.make_pa(B.OraclePSAlign, draft, events, P)
+def muts_of(a, b):
+    ms = synth.random_point_mutations(np.random.default_rng(a + 1), make(a, b).sequence, 60)
+    for m in ms: m.start += a
+    return ms
+got = psdist.variant_regions(regions, make, muts_of)
+want = [variant_region(make(a, b), muts_of(a, b), region_start=a) for a, b in regions]
+same = all(len(g) == len(w) and all((x.start, x.orig, x.mut, x.score) == (y.start, y.orig, y.mut, y.score) for x, y in zip(g, w)) for g, w in zip(got, want))
+ok = psdist.max_over_ranks(0.0 if same else 1.0)
+if rank == 0:
+    print(json.dumps({"world": world, "equal": ok == 0.0, "n": [len(g) for g in got], "first_start": [g[0].start for g in got]}), flush=True)
+psdist.finalize()
+'''
+
+
+def test_variant_regions_shards_by_region_or_by_event():
+    """`poreseq variant` over the ranks: three regions on two ranks shard by region; ONE region on two ranks shards its events (no rank
+    idles) — both equal the single-process scores bit for bit, starts absolute (Variant.py:66-95; oracle backend, gloo)"""
+    global WORKER
+    keep, WORKER = WORKER, WORKER_VARIANT
+    try:
+        res = {}
+        for nreg in (3, 1):
+            os.environ["NREG"] = str(nreg)
+            res[nreg] = (run_world(1), run_world(2))
+    finally:
+        WORKER = keep
+        os.environ.pop("NREG", None)
+    for nreg, (one, two) in res.items():
+        assert one["equal"] and two["equal"] and two["world"] == 2, nreg
+        assert one["n"] == two["n"] == [60] * nreg and one["first_start"] == two["first_start"]
+    assert res[3][0]["first_start"][2] >= 2000                      # absolute starts
+
+
 def test_stream_batches_keeps_item_order_and_reraises():
     """poreseq_amd.dist.stream_batches: items stream through `in_flight` host threads (a thread takes the next item when its own is
     done), results come back in item order, the first exception is re-raised; no GPU involved (the workers' entry hint is moot here)."""

@@ -22,7 +22,7 @@ def test_bench_under_torchrun_single_rank():
     line = [l for l in out.decode().splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["unit"] == "kb/s" and r["scaling"] == "weak"
-    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0 and r["roofline"]["kernel"] in ("k_fill", "k_sweep")
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0 and r["roofline"]["kernel"] in ("k_fill", "k_sweep", "k_sweeps", "k_sweep_w", "k_sweeps_w")
     assert r["north_star_1kb"]["lock_step_kb_s"] > r["north_star_1kb"]["single_region_kb_s"] > 0
     assert r["config"]["batches_in_flight"] == 2 and r["single_region_s"] > 0
     assert r["accuracy"]["consensus_percent"] > 97.0
