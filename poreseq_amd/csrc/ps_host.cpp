@@ -560,8 +560,11 @@ size_t slab_bytes() {
 }
 // bytes of full matrices one dense call may place: the slab, or PORESEQ_MAX_BATCH_GB when set (tests: tiny budgets)
 double dense_cap_bytes() {
-    if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return std::min(g * 1e9, (double)slab_bytes()); }
-    return (double)slab_bytes();
+    // (the smallest slab actually allocated, when one came out smaller than planned: sub-batches are cut to fit any of them)
+    size_t cap = slab_bytes();
+    { std::lock_guard<std::mutex> lk(g_slab_mu); for (const Slab* sl : g_slabs) cap = std::min(cap, sl->bytes); }
+    if (const char* e = getenv("PORESEQ_MAX_BATCH_GB")) { const double g = atof(e); if (g > 0) return std::min(g * 1e9, (double)cap); }
+    return (double)cap;
 }
 void SlabHold::release() {
     if (!s) return;
@@ -1376,9 +1379,15 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     if (!sparse && R == 1) for (int e = 0; e < as[0]->E; e++) lone_need += ((double)as[0]->n[e] + as[0]->states.size() + 1 + MAT_FRONT + MAT_BACK) * std::min(1024, 2 * as[0]->par.realign_width + 74) * 36.0;
     if (!sparse && lone_need <= (double)slab_bytes()) {
         PS_TRY(slab_acquire(&slab));
-        if (rt->prof_on) rt->prof["slab"].launches++;   // (dense calls that took a slab: a host-side count)
-        slab.drain = rt->stream;
-        b.ext = slab.p; b.ext_bytes = R > 1 ? std::min(slab.bytes, (size_t)dense_cap_bytes()) : slab.bytes;
+        if (R == 1 && lone_need > (double)slab.bytes) {
+            // the slab this call was handed is smaller than the plan (a device fuller than expected: slab_acquire's fallback sizes) and a
+            // single AlignData cannot be split: its matrices go to the runtime's own pools, as those beyond a planned slab do
+            slab.release();
+        } else {
+            if (rt->prof_on) rt->prof["slab"].launches++;   // (dense calls that took a slab: a host-side count)
+            slab.drain = rt->stream;
+            b.ext = slab.p; b.ext_bytes = R > 1 ? std::min(slab.bytes, (size_t)dense_cap_bytes()) : slab.bytes;
+        }
         tk.lap("slab wait");
     }
     PS_TRY(b.build(rt, specs, 2, extra));
