@@ -193,16 +193,17 @@ int ps_debug_fill(ps_align* a, int32_t ev, int32_t direction, double* main, doub
                   uint8_t* step_main, uint8_t* step_stay);
 
 /* Tuning knob (process-wide): forward-only alignment batches — ScoreAlignments, FindMutations' candidate sequences — of at
- * least `min_alignments` jobs run one wavefront per alignment (ps_sweep.hip); smaller ones a workgroup per alignment (k_fill),
+ * least `min_alignments` jobs run as strip sweeps (ps_sweep.hip / ps_sweepw.hip: one to four wavefronts per alignment, ps_set_sweep_form);
+ * smaller ones a workgroup per alignment (k_fill),
  * which finishes a lone small batch sooner.  Results do not depend on it.  Negative: back to the default
  * (PORESEQ_SWEEP_MIN, else 400). */
 int ps_set_sweep_min(int32_t min_alignments);
 /* The same for Alignment::update batches (ScoreMutations: a forward and a backward sweep per alignment, with score matrices):
- * from `min_sweeps` sweeps on, one wavefront per sweep.  Negative: the default (PORESEQ_SWEEP2_MIN, else never:
+ * from `min_sweeps` sweeps on, strip sweeps with full records.  Negative: the default (PORESEQ_SWEEP2_MIN, else never:
  * their records cap a launch at a few hundred sweeps, where a workgroup per sweep is twice as fast — DESIGN.md section 4). */
 int ps_set_sweep2_min(int32_t min_sweeps);
 /* Alignment::update batches whose edit lists read at most a quarter of the matrix columns (every ScoreMutations call of a consensus
- * schedule except Refine's point edits at every position): from `min_sweeps` sweeps on, one wavefront per sweep that stores the
+ * schedule except Refine's point edits at every position): from `min_sweeps` sweeps on, strip sweeps that store the
  * {main, stay} records of the columns scoreMutation / columnMax will read (cpp/Alignment.cpp:447-512, cpp/Alignment.h:181-214) and
  * nothing else of the score matrices.  Negative: the default (PORESEQ_SPARSE_MIN, else 160).  Results do not depend on it. */
 int ps_set_sparse_min(int32_t min_sweeps);
@@ -219,7 +220,8 @@ int ps_set_sweep_form(int32_t rows_per_lane, int32_t wavefronts);
 int ps_set_device_fraction(double fraction);
 
 /* Hot-kernel instrumentation for bench.py: accumulated HIP-event time (ms), launches and
- * algorithmic bytes of the named kernel class ("fill" = k_fill, "sweep" = k_sweep / k_sweep2, "score", "viterbi", "sw") since reset. */
+ * algorithmic bytes of the named kernel class ("fill" = k_fill, "sweep" = the strip sweeps k_sweep / k_sweeps / k_sweep2 and their _w builds,
+ * "score", "viterbi", "sw") since reset; host-side launch counts by form under "sweep_w2", "sweep_w4", "sweep_kept", "sw_pk8", "slab". */
 /* ps_prof_enable(1) makes every hot-kernel launch be bracketed by HIP events on the library's stream
  * (one extra synchronisation per launch: use it in a separate, untimed pass); ps_prof_enable(2) queues the
  * event pairs instead and reads them when the profile is asked for (no synchronisation per launch: usable
