@@ -489,7 +489,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 8 :
 // the packed fill (8 columns per lane, 8 waves) with the traceback of the 8-column build
 static int sw_run_pk(Runtime* rt, hipStream_t st, int np, int nss, const SwPair* d_pairs, const char* d_chars, int* d_row, int* d_col,
                      int* d_blk, int* d_prog, int* d_ticket, int* d_out, int* d_res) {
-    hipLaunchKernelGGL((k_sw_fill_pk<SWW>), dim3(nss, np), dim3(64 * SWW), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_res);
+    // PORESEQ_SW_LDS_PAD_KB (tuning): dynamic LDS a strip's workgroup claims on top of its own, i.e. a cap on the strips resident per CU: a
+    // batch of 340 pairs is 1 700 chained strips of eight waves that mostly wait for their left neighbours and would take every free wave slot
+    static const size_t pad = getenv("PORESEQ_SW_LDS_PAD_KB") ? (size_t)atoi(getenv("PORESEQ_SW_LDS_PAD_KB")) * 1024 : 0;
+    hipLaunchKernelGGL((k_sw_fill_pk<SWW>), dim3(nss, np), dim3(64 * SWW), pad, st, d_pairs, d_chars, d_row, d_col, d_blk, d_prog, d_ticket, d_res);
     PS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_sw_trace<8>, dim3(np), dim3(64), 0, st, d_pairs, d_chars, d_row, d_col, d_blk, d_out, d_res);
     PS_HIP(hipGetLastError());
