@@ -124,3 +124,30 @@ def test_hip_event_sharded_scoring_and_deltas():
     assert np.array_equal(s, np.array([w.score for w in want]))
     got = psdist.score_mutations_event_sharded(mk(PSAlign), muts)
     assert [g.score for g in got] == [w.score for w in want]
+
+
+@pytest.mark.gpu
+def test_hip_variant_regions_single_rank_equals_oracle():
+    """`poreseq variant` through the package driver on the HIP library (one rank: the region-sharded branch; the event-sharded branch and
+    both on two ranks run on gloo in tests/test_dist.py): absolute starts, scores bit-identical to the oracle's per-region ScoreMutations"""
+    import copy
+    import numpy as np
+    import backends as B
+    from poreseq_amd import dist as psdist, synth
+    from poreseq_amd.consensus import variant_region
+    from poreseq_amd.poreseqcpp import PSAlign
+    from poreseq_amd.util import DEFAULT_PARAMS
+    P = dict(DEFAULT_PARAMS, verbose=0, scoring_width=100.0)
+    regions = [(0, 900), (5000, 5600), (9000, 10300)]
+    made = {(a, b): synth.make_region(b - a, 6, 5100 + a, B.oracle_swalign, P) for a, b in regions}
+
+    def muts_of(a, b):
+        ms = synth.random_point_mutations(np.random.default_rng(a + 7), made[(a, b)][0], 120)
+        for m in ms:
+            m.start += a
+        return ms
+    got = psdist.variant_regions(regions, lambda a, b: B.make_pa(PSAlign, made[(a, b)][0], copy.deepcopy(made[(a, b)][1]), P), muts_of)
+    for (a, b), g in zip(regions, got):
+        want = variant_region(B.make_pa(B.OraclePSAlign, made[(a, b)][0], copy.deepcopy(made[(a, b)][1]), P), muts_of(a, b), region_start=a)
+        assert [(x.start, x.orig, x.mut, x.score) for x in g] == [(y.start, y.orig, y.mut, y.score) for y in want]
+        assert min(x.start for x in g) >= a
