@@ -1,3 +1,6 @@
+#!/bin/bash
+# A/B of the strip sweep's form in the bench: one and two wavefronts per sweep, alternating, three timed steps each (one box, one call).
+# usage (GPU box): bash tools/ab_nw.sh
 for cfg in "PORESEQ_SWEEP_NW=1" "PORESEQ_SWEEP_NW=2" "PORESEQ_SWEEP_NW=1" "PORESEQ_SWEEP_NW=2"; do
   echo "== $cfg"
   env $cfg timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu --no-extras 2>/dev/null | python -c "

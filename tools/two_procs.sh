@@ -1,3 +1,6 @@
+#!/bin/bash
+# two bench processes on ONE device at once (7 batches of 20 regions each, half of the device's memory plan each): is the device or the
+# process (host threads, hardware queues) what caps the bench?  usage (GPU box): bash tools/two_procs.sh  -> gpurun_out/two_a.json, two_b.json
 export PORESEQ_DEVICE_FRACTION=0.5
 (timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu --no-extras --regions-per-gpu 140 --batches-in-flight 7 > gpurun_out/two_a.json 2>/dev/null &)
 timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu --no-extras --regions-per-gpu 140 --batches-in-flight 7 > gpurun_out/two_b.json 2>/dev/null
