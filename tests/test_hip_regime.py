@@ -112,7 +112,7 @@ def test_first_call_of_a_fresh_process_is_a_kept_column_sweep(nw):
 def test_windows_that_leave_one_lane_idle_match_the_oracle():
     """A strip sweep's window (strips in band on one step) may take all lanes of the sweep but one (sweep_win_max: the lane above the lowest
     strip in band must hold an out-of-band strip).  Band widths scanned around the point where the window of K = 4 rows per lane reaches 63 of
-    64 lanes (one wavefront) and 127 of 128 (two): forward and backward DP matrices with step codes (ps_debug_fill) and ScoreEvents equal
+    64 lanes (one wavefront), 127 of 128 (two) and, at K = 2, 255 of 256 (four): forward and backward DP matrices with step codes (ps_debug_fill) and ScoreEvents equal
     the oracle at every width, and the trace shows that the maximal windows were among them."""
     import os, re, subprocess, sys
     code = (
@@ -123,8 +123,8 @@ def test_windows_that_leave_one_lane_idle_match_the_oracle():
         "from poreseq_amd.util import DEFAULT_PARAMS\n"
         "hip, orc = _capi.load_hip(), B.oracle_api()\n"
         "hip.set_sweep_min(0); hip.set_sweep2_min(0); hip.set_sparse_min(0)\n"
-        "for nw, widths, L in ((1, range(144, 160), 900), (2, range(296, 312, 2), 1500)):\n"
-        "    hip.set_sweep_form(4, nw)\n"
+        "for nw, K, widths, L in ((1, 4, range(144, 160), 900), (2, 4, range(296, 312, 2), 1500), (4, 2, range(356, 380, 2), 1800)):\n"
+        "    hip.set_sweep_form(K, nw)\n"
         "    for W in widths:\n"
         "        P = dict(DEFAULT_PARAMS, verbose=0, realign_width=float(W))\n"
         "        draft, events, truth = synth.make_region(L, 2, 6000 + W, B.oracle_swalign, P)\n"
@@ -143,5 +143,5 @@ def test_windows_that_leave_one_lane_idle_match_the_oracle():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, env=dict(os.environ, PORESEQ_TRACE="1"))
     assert r.returncode == 0 and "WINDOWS-OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
     wins = {(int(k), int(n), int(w)) for k, n, w in re.findall(r"K = (\d+) on (\d) wavefronts, widest window (\d+) strips", r.stderr)}
-    assert (4, 1, 63) in wins and (4, 2, 127) in wins, sorted(wins)            # the windows that use every lane but one did occur
+    assert (4, 1, 63) in wins and (4, 2, 127) in wins and (2, 4, 255) in wins, sorted(wins)   # the windows that use every lane but one did occur
     assert any(k > 4 for k, n, w in wins)                                      # and wider ones took the next strip height
