@@ -323,11 +323,12 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                     sm = cSKIP == nm ? 0u : sm;
                     sm = nm > 0.0 ? sm : 0u;
                 }
+                // (a row outside the band carries both "score <= 0" bits — the walker stops there before it reads the step — as its scores
+                //  are the absent-cell value: `masked score > 0` = in band and `score > 0`, the mask joined in scalar registers)
+                const bool mpos = act && nm > 0.0, spos = act && ns > 0.0;
                 const double nmx = keep_or_absent(nm, act), nsx = keep_or_absent(ns, act);
                 if (DIR == 0) {
-                    // (a row outside the band carries both "score <= 0" bits — the walker stops there before it reads the step — because
-                    //  its scores are the absent-cell value; its step bits are whatever the selects left)
-                    unsigned w = sm | (ss << 3) | (nmx > 0.0 ? 0u : 32u) | (nsx > 0.0 ? 0u : 64u);   // (every constant an inline operand)
+                    unsigned w = sm | (ss << 3) | (mpos ? 0u : 32u) | (spos ? 0u : 64u);   // (every constant an inline operand; the step bits of a row outside the band are whatever the selects left)
                     asm volatile("" : "+v"(w));                      // keep the byte's shift out of the selects' constants (a VGPR per shifted literal otherwise)
                     if ((r & 3) == 0) cwp[r >> 2] = w; else cwp[r >> 2] |= w << (8 * (r & 3));
                 }
@@ -344,8 +345,9 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                     crun = fmax(crun, rx);
                 }
                 if (MODE == 2) {
-                    if (DEFER_REC) { pnm[r] = nm; pns[r] = ns; }
-                    else if (kstore) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){nm, ns};   // (a cell in band: nm >= 0)
+                    // (the masked values: a cell in band is stored as it is, a row outside the band lands in the column's padding)
+                    if (DEFER_REC) { pnm[r] = nmx; pns[r] = nsx; }
+                    else if (kstore) *(PS_GLOBAL v2d*)(recp + r * 16) = (v2d){nmx, nsx};
                     crun = fmax(crun, nmx);
                 }
                 if (DIR == 0) {
