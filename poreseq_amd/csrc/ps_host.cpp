@@ -12,6 +12,7 @@
 #include <cstring>
 #include <array>
 #include <functional>
+#include <iterator>
 #include <numeric>
 #include <mutex>
 #include <deque>
@@ -1280,9 +1281,11 @@ static void plan_tables(const Align* a, const std::vector<Mut>& muts, EditPlan* 
 
 // ScoreMutations, cpp/MakeMutations.cpp:23-69, for several AlignData at once: one realign launch chain over all their
 // events (forward + backward of one event share a workgroup), then the edit scoring of each
+static int score_mutations_planned(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
+                                   const std::vector<std::vector<Mut>*>& outs, const std::vector<double*>* delta_out, std::vector<EditPlan>& plan);
+
 int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
                           const std::vector<std::vector<Mut>*>& outs, const std::vector<double*>* delta_out) {
-    Tick tk("score_mutations");
     const int R = (int)as.size();
     std::vector<EditPlan> plan(R);
     par_for(R, [&](int k) {   // (a Refine list is 80 000 edits per region: copied and sized side by side)
@@ -1295,6 +1298,16 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         if (plan[k].rc != PS_OK) return fail(plan[k].rc, "negative mutation start");
         if (plan[k].ncolmax > 64 && as[k]->par.scoring_width > 511) return fail(PS_ERR_UNSUPPORTED, "edit longer than 58 bases with scoring_width > 511");
     }
+    return score_mutations_planned(rt, as, muts, outs, delta_out, plan);
+}
+
+// `plan`: every list sized (plan_edits) and `outs` initialised — once per call: the sub-batches of a call that does not fit a slab or the
+// runtime's share, and the halves of one whose bands came out wider than guessed, take their regions' plans with them (moved: the
+// caller returns right behind them) instead of copying and sizing 80 000 edits per region again
+static int score_mutations_planned(Runtime* rt, const std::vector<Align*>& as, const std::vector<const std::vector<Mut>*>& muts,
+                                   const std::vector<std::vector<Mut>*>& outs, const std::vector<double*>* delta_out, std::vector<EditPlan>& plan) {
+    Tick tk("score_mutations");
+    const int R = (int)as.size();
     // Which columns of the score matrices will the edit lists read?  A short list (FindMutations' found edits, the rounds of
     // MakeMutations' recursion: tens to hundreds of edits per region) reads a few percent of them: the fills then run as strip
     // sweeps that keep those columns only (ps_sweep.hip, k_sweeps) — a few MB per alignment instead of 2 x 110 MB.  A list that
@@ -1306,7 +1319,7 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
     for (int k = 0; k < R && sparse; k++) {
         const Align* a = as[k];
         const int C = (int)a->states.size();
-        plan_keep(a, &plan[k]);
+        if (plan[k].keep[0].empty()) plan_keep(a, &plan[k]);   // (C + 2 entries once computed)
         if (std::max(plan[k].nkeep[0], plan[k].nkeep[1]) > sparse_frac * C) sparse = false;
         const int K = sweep_guess_k(a->par.realign_width);
         if (!K) sparse = false;
@@ -1321,24 +1334,24 @@ int score_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std:
         fprintf(stderr, "[ps] score_mutations: %d regions, %d events, %zu edits, kept columns <= %.3f of a matrix: %s\n", R, njobs_all, M, fr, sparse ? "kept columns" : "full matrices");
     }
     tk.lap("edit sizes");
+    auto sub = [&](size_t k0, size_t k1) {   // regions k0 .. k1 - 1 as a call of their own, with their plans
+        std::vector<double*> dsub;
+        if (delta_out) dsub.assign(delta_out->begin() + k0, delta_out->begin() + k1);
+        std::vector<EditPlan> psub(std::make_move_iterator(plan.begin() + k0), std::make_move_iterator(plan.begin() + k1));
+        return score_mutations_planned(rt, std::vector<Align*>(as.begin() + k0, as.begin() + k1),
+                                       std::vector<const std::vector<Mut>*>(muts.begin() + k0, muts.begin() + k1),
+                                       std::vector<std::vector<Mut>*>(outs.begin() + k0, outs.begin() + k1), delta_out ? &dsub : nullptr, psub);
+    };
     auto halves = [&]() {
         const size_t h = as.size() / 2;
-        std::vector<double*> d0, d1;
-        if (delta_out) { d0.assign(delta_out->begin(), delta_out->begin() + h); d1.assign(delta_out->begin() + h, delta_out->end()); }
-        PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin(), as.begin() + h), std::vector<const std::vector<Mut>*>(muts.begin(), muts.begin() + h),
-                                     std::vector<std::vector<Mut>*>(outs.begin(), outs.begin() + h), delta_out ? &d0 : nullptr));
-        return score_mutations_multi(rt, std::vector<Align*>(as.begin() + h, as.end()), std::vector<const std::vector<Mut>*>(muts.begin() + h, muts.end()),
-                                     std::vector<std::vector<Mut>*>(outs.begin() + h, outs.end()), delta_out ? &d1 : nullptr);
+        PS_TRY(sub(0, h));
+        return sub(h, as.size());
     };
     if (sparse && R > 1 && sparse_bytes > device_share_bytes()) return halves();
     if (!sparse && fit_share(as, 0, 2) < as.size()) {   // sub-batches that fit this runtime's share of the device
         for (size_t k0 = 0; k0 < as.size();) {
             const size_t k1 = fit_share(as, k0, 2);
-            std::vector<double*> dsub;
-            if (delta_out) dsub.assign(delta_out->begin() + k0, delta_out->begin() + k1);
-            PS_TRY(score_mutations_multi(rt, std::vector<Align*>(as.begin() + k0, as.begin() + k1),
-                                         std::vector<const std::vector<Mut>*>(muts.begin() + k0, muts.begin() + k1),
-                                         std::vector<std::vector<Mut>*>(outs.begin() + k0, outs.begin() + k1), delta_out ? &dsub : nullptr));
+            PS_TRY(sub(k0, k1));
             k0 = k1;
         }
         return PS_OK;
