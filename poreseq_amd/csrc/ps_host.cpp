@@ -1186,7 +1186,7 @@ namespace {
 // host-side description of one AlignData's edit list for k_old / k_score
 struct EditPlan {
     int M = 0, ncolmax = 1, extra = 0, nr0 = 0;
-    std::vector<int> start, mlen, cm, ncol, skip, oldidx, states, r0s, cls[4];
+    std::vector<int> start, mlen, cm, ncol, skip, oldidx, states, r0s, cls[SCORE_CLASSES];
     std::vector<int> keep[2];   // per direction: kept-column index of column 0 .. C + 1, or -1 (plan_keep)
     int nkeep[2] = {0, 0};
     int rc = PS_OK;
@@ -1273,9 +1273,10 @@ static void plan_tables(const Align* a, const std::vector<Mut>& muts, EditPlan* 
         p->oldidx[i] = at;
     }
     p->nr0 = (int)p->r0s.size();
+    static const int lim7 = getenv("PORESEQ_NO_SCORE7") ? -1 : 7;   // (tuning / A-B: point edits on the 8-lane class as before round 5)
     for (int i = 0; i < M; i++) {
         const int nc = p->ncol[i];
-        p->cls[nc <= 8 ? 0 : nc <= 16 ? 1 : nc <= 32 ? 2 : 3].push_back(i);
+        p->cls[nc <= lim7 ? 4 : nc <= 8 ? 0 : nc <= 16 ? 1 : nc <= 32 ? 2 : 3].push_back(i);
     }
 }
 
@@ -1445,7 +1446,7 @@ static int score_mutations_planned(Runtime* rt, const std::vector<Align*>& as, c
         sa.nitems_per_job = p.M; sa.ncolmax = p.ncolmax; sa.ws = as[k]->par.scoring_width; sa.nr0 = p.nr0;
         sa.m_start = push(p.start); sa.m_mlen = push(p.mlen); sa.m_cm = push(p.cm); sa.m_ncol = push(p.ncol);
         sa.m_skip = push(p.skip); sa.m_oldidx = push(p.oldidx); sa.m_states = push(p.states); sa.r0 = push(p.r0s);
-        for (int q = 0; q < 4; q++) { sa.cls_items[q] = push(p.cls[q]); sa.cls_count[q] = (int)p.cls[q].size(); }
+        for (int q = 0; q < SCORE_CLASSES; q++) { sa.cls_items[q] = push(p.cls[q]); sa.cls_count[q] = (int)p.cls[q].size(); }
         sa.old = dd; dd += (size_t)as[k]->E * std::max(p.nr0, 1);
         sa.delta = dd; dd += (size_t)as[k]->E * std::max(p.M, 1);
         sa.score = score0 + score_at[k];

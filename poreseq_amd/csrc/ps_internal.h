@@ -242,9 +242,12 @@ struct ScoreArgs {
     int64_t oldall_pitch, maxS;
     double* delta;             // [njobs][M]
     double* score;             // [M]
-    const int* cls_items[4];   // device lists of edit indices whose new-column count fits 8 << k lanes (k = 3: chunked, any size)
-    int cls_count[4];
+    // device lists of edit indices by new-column count: class k < 4 fits 8 << k lanes (k = 3: chunked, any size), class 4 fits 7 (point
+    // edits, len(mut) <= 1: 6 or 7 new columns — nine edits to a wave instead of eight)
+    const int* cls_items[5];
+    int cls_count[5];
 };
+constexpr int SCORE_CLASSES = 5;
 int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs* d_sas, const std::vector<ScoreArgs>& h_sas);
 int launch_begin(Runtime* rt, const BatchD& b);
 int launch_gather_best(Runtime* rt, const BatchD& b, double* out);   // out[job] = the job's forward maxScore (JobOut.best)

@@ -803,7 +803,23 @@ __global__ __launch_bounds__(256) void k_fill_like(BatchD b) {
 // columnMax(raf, rab) on the filled matrices (cpp/Alignment.h:181-214); cooperative over `nl` lanes
 // Only rows where both columns are in band can exceed the two running maxima (stay <= main <= max).
 // ------------------------------------------------------------------------------------------------
-__device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, int lane, int nl) {
+// maximum over the NL lanes of a lane's group (groups of NL consecutive lanes from lane 0 of the wave on; wl: the lane in its wave).
+// NL = 7 (nine groups to a wave, lane 63 idle): three rotations within the group — by 1, 2, 4: every lane then holds the maximum
+// of 8 >= NL cyclically consecutive members.
+template <int NL>
+__device__ __forceinline__ double group_max(double v, int wl) {
+    if ((NL & (NL - 1)) == 0) {
+        for (int off = 1; off < NL; off <<= 1) v = fmax(v, __shfl_xor(v, off));
+    } else {
+        const int g0 = (wl / NL) * NL, c = wl - g0;
+        for (int off = 1; off < NL; off <<= 1) v = fmax(v, __shfl(v, min(g0 + (c + off) % NL, 63)));
+    }
+    return v;
+}
+
+template <int NL>
+__device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, int lane, int wl) {
+    constexpr int nl = NL;
     const int C = J.C, n0 = J.n0;
     if ((unsigned)raf >= (unsigned)(C + 1)) raf = C;
     if ((unsigned)rab >= (unsigned)(C + 1)) rab = C;
@@ -821,7 +837,7 @@ __device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, 
         if (rab > 0) bv = b.rec[rec_index(J, 1, jb, rab, b0)];
         sm = fmax(sm, fmax(fv.x + bv.x, fv.y + bv.y));
     }
-    for (int off = 1; off < nl; off <<= 1) sm = fmax(sm, __shfl_xor(sm, off));
+    sm = group_max<NL>(sm, wl);
     sm = fmax(sm, b.pm[J.col_off[0] + raf]);
     sm = fmax(sm, b.pm[J.col_off[1] + rab]);
     return sm;
@@ -834,7 +850,7 @@ __global__ __launch_bounds__(64) void k_old(BatchD b, const ScoreArgs* __restric
     const JobD& J = b.jobs[a.job0 + blockIdx.y];
     if (J.out->inert) return;
     const int r0 = a.r0[blockIdx.x];
-    const double v = colmax_pair(b, J, r0, J.C - r0 + 1, threadIdx.x, 64);
+    const double v = colmax_pair<64>(b, J, r0, J.C - r0 + 1, threadIdx.x, threadIdx.x);
     if (threadIdx.x == 0) a.old[(size_t)blockIdx.y * a.nr0 + blockIdx.x] = v;
 }
 
@@ -1015,8 +1031,8 @@ __global__ __launch_bounds__(256) void k_oldfin(BatchD b, const ScoreArgs* __res
 //  sweep keeps on SIMD 0 and 1, so k_score ran only on CUs without a fill: 1.07 ms per launch in the bench against 0.25 ms alone)
 template <int G, bool FD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_score(BatchD b, const ScoreArgs* __restrict__ A) {
-    constexpr int IPW = 64 / G;
-    constexpr int CLS = G == 8 ? 0 : (G == 16 ? 1 : (G == 32 ? 2 : 3));
+    constexpr int IPW = 64 / G;   // (G = 7: nine items to a wave, lane 63 idle)
+    constexpr int CLS = G == 7 ? 4 : G == 8 ? 0 : (G == 16 ? 1 : (G == 32 ? 2 : 3));
     const ScoreArgs& a = A[blockIdx.z];
     const int nitems = a.cls_count[CLS];
     if ((int)blockIdx.y >= a.njobs || (int)blockIdx.x * 4 * IPW >= nitems) return;
@@ -1027,7 +1043,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const int job = blockIdx.y;   // within the AlignData's own jobs, which start at a.job0 in the batch
     const JobD& J = b.jobs[a.job0 + job];
     const int it = (blockIdx.x * 4 + wave) * IPW + g;
-    const bool have = it < nitems;
+    const bool have = it < nitems && g < IPW;
     const int m = have ? items[it] : 0;
     const int n0 = J.n0, C = J.C, WS = a.ws;
     const bool live = have && !J.out->inert && !a.m_skip[m];
@@ -1202,18 +1218,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         }
         // MaxInfo: max over the new columns up to and including the target
         double cmx = (mine && cc <= trel) ? colmax : 0.0;
-        for (int off = 1; off < G; off <<= 1) cmx = fmax(cmx, __shfl_xor(cmx, off));
+        cmx = group_max<G>(cmx, lane);
         fmaxv = fmax(fmaxv, cmx);
         // next chunk continues from this chunk's last column
         pc0 = __shfl(i0, g * G + max(lastcol, 0)); pc1 = __shfl(i1, g * G + max(lastcol, 0));
         __builtin_amdgcn_wave_barrier();
     }
     // gather the target lane's row maximum
-    double tmx = tm;
-    for (int off = 1; off < G; off <<= 1) tmx = fmax(tmx, __shfl_xor(tmx, off));
+    const double tmx = group_max<G>(tm, lane);
     double now;
     if (trel < 0) {
-        now = !live ? 0.0 : colmax_pair(b, J, sidx, backind, c, G);   // no new column: the spliced copy is the target
+        now = !live ? 0.0 : colmax_pair<G>(b, J, sidx, backind, c, lane);   // no new column: the spliced copy is the target
     } else {
         now = fmax(0.0, tmx);
         now = fmax(now, fmaxv);
@@ -1420,7 +1435,7 @@ int launch_begin(Runtime* rt, const BatchD& b) {
 // per kernel over all of them — grid.z (k_reduce: grid.y) is the AlignData, blocks past an AlignData's own sizes leave at once
 int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs* d_sas, const std::vector<ScoreArgs>& h_sas) {
     const int R = (int)h_sas.size();
-    int maxE = 0, maxnr0 = 0, maxnr0_all = 0, maxM = 0, cls_max[4] = {0, 0, 0, 0};
+    int maxE = 0, maxnr0 = 0, maxnr0_all = 0, maxM = 0, cls_max[SCORE_CLASSES] = {0, 0, 0, 0, 0};
     int64_t maxS = 0;
     bool any_all = false, any_old = false;
     for (const ScoreArgs& a : h_sas) {
@@ -1428,7 +1443,7 @@ int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs* d_sas, const std
         maxE = std::max(maxE, a.njobs); maxM = std::max(maxM, a.nitems_per_job);
         if (a.nr0 > 0 && a.oldall) { any_all = true; maxS = std::max(maxS, a.maxS); maxnr0_all = std::max(maxnr0_all, a.nr0); }
         else if (a.nr0 > 0) { any_old = true; maxnr0 = std::max(maxnr0, a.nr0); }
-        for (int k = 0; k < 4; k++) cls_max[k] = std::max(cls_max[k], a.cls_count[k]);
+        for (int k = 0; k < SCORE_CLASSES; k++) cls_max[k] = std::max(cls_max[k], a.cls_count[k]);
     }
     if (!maxE || !maxM) return PS_OK;
     if (any_all) {
@@ -1444,14 +1459,14 @@ int launch_score(Runtime* rt, const BatchD& b, const ScoreArgs* d_sas, const std
         PS_LAUNCH_CHECK();
     }
     prof_begin(rt);
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < SCORE_CLASSES; k++) {
         const int n = cls_max[k];
         if (!n) continue;
-        const int G = 8 << k, ipb = 4 * (64 / G);
+        const int G = k == 4 ? 7 : 8 << k, ipb = 4 * (64 / G);
         dim3 grid((n + ipb - 1) / ipb, maxE, R), block(256);
 #define PS_SCORE(GG) do { if (b.fastdiv) hipLaunchKernelGGL((k_score<GG, true>), grid, block, 0, rt->stream, b, d_sas); \
                           else hipLaunchKernelGGL((k_score<GG, false>), grid, block, 0, rt->stream, b, d_sas); } while (0)
-        if (k == 0) PS_SCORE(8); else if (k == 1) PS_SCORE(16); else if (k == 2) PS_SCORE(32); else PS_SCORE(64);
+        if (k == 4) PS_SCORE(7); else if (k == 0) PS_SCORE(8); else if (k == 1) PS_SCORE(16); else if (k == 2) PS_SCORE(32); else PS_SCORE(64);
 #undef PS_SCORE
         PS_LAUNCH_CHECK();
     }
