@@ -6,6 +6,10 @@
 #include "ps_dev.h"
 #include "ps_host.h"
 
+#ifndef PS_SWEEP_STRAIGHT
+#define PS_SWEEP_STRAIGHT 1
+#endif
+
 namespace ps {
 
 // ---- byte layout of one step's codes: row groups ("planes") of 16 / 8 / 4 / 2 / 1 rows, each [NL lanes][rows of the group] ----
@@ -256,9 +260,11 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         load_levels(ql1);
         model_row(a1.sc, mr);
         pend = live;
-        if (live) {
+        // (a step without a strip in band — the steps a last round of three adds behind T - 1 — runs the cells too, on no band: a uniform
+        //  branch around them makes every loop-carried value a phi of two definitions, eight register copies per step)
+        if ((PS_SWEEP_STRAIGHT && MODE != 1) || live) {   // (MODE 1 stores a record per cell and step: behind T - 1 there is no room for them)
             const int base = q * K + 1;
-            const bool valid = j >= 1 && j <= C && a0.sc >= 0;     // (a column whose 5-mer is invalid is all zero: no cell takes part, cpp/Alignment.cpp:162-163)
+            const bool valid = live && j >= 1 && j <= C && a0.sc >= 0;     // (a column whose 5-mer is invalid is all zero: no cell takes part, cpp/Alignment.cpp:162-163)
             const int ra = valid ? a0.bd.z - base : K, rb = valid ? a0.bd.w - base : -1;   // band rows relative to the strip
             const int rc = a0.bd.x - base, rd_ = a0.bd.y - base;                          // previous column's band
             const bool pzero = a0.sp < 0;                            // previous column invalid (or column 0): its scores read as zero
@@ -269,7 +275,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             const double lbefore = lbest;
             double crun = 0.0;                                       // (MODE > 0) the lane's share of its column's maximum
             PS_GLOBAL char* recp = rec + ((size_t)t * K * NL + lane) * 16;
-            const bool kept = MODE == 2 && a0.kc >= 0 && j >= 1 && j <= C;
+            const bool kept = MODE == 2 && live && a0.kc >= 0 && j >= 1 && j <= C;
             // (MODE 2) a lane whose column is kept stores all K rows of its strip when the strip meets the column's band: a row outside
             // the band lands in the K - 1 records of padding in front of / behind the column's band (sweep_prepare), which nobody reads
             const bool kstore = kept && ra < K && rb >= 0;
@@ -360,7 +366,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             bot_m = um; bot_s = us; bot_e = ue;
             if (DIR == 0) lbt = lbest > lbefore ? t : lbt;
             if (MODE) atomicMax(&ring[(unsigned)j & (RING - 1)], (unsigned long long)__double_as_longlong(crun));   // (scores >= 0 order like their bit patterns; 0 is a no-op)
-            if (MODE && t >= next_flush) {
+            if (MODE && live && t >= next_flush) {
                 // the maxima of completed columns: everything left of the column the highest strip in band is working on (every wave's
                 // contributions to them were made in earlier steps, i.e. before the barrier this step started behind)
                 const int jdone = min(t - QHI[t], C + 1);
