@@ -48,11 +48,22 @@ __device__ __forceinline__ int64_t rec_index(const JobD& J, int dir, int i, int 
     return J.mat_off[dir] + (int64_t)(i + j) * J.P + i % J.P;
 }
 
+// the value of the lane before (lane 0 of the wave reads zero: its callers give a group's first lane a value of its own).  With
+// bound_ctrl the instruction needs no previous value of its destination — two register copies per use less than `old = v`.
 __device__ __forceinline__ double wave_shr1(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
+}
+
+// `x` where keep, else a huge negative FINITE number: only the high word is selected (0xFFEFFFFF: -1.797e308 whatever the low word
+// holds).  It stands for "no cell here" exactly as -infinity does — it loses every maximum against a real score (>= 0), against the
+// floors 0 and -1e300 and in every `>` test, adding an emission or a transition term leaves it where it is, and two of them are never
+// added — at one v_cndmask instead of two.
+__device__ __forceinline__ double keep_or_absent(double x, bool keep) {
+    const int hi = keep ? __double2hiint(x) : (int)0xFFEFFFFF;
+    return __hiloint2double(hi, __double2loint(x));
 }
 
 

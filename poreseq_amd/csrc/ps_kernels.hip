@@ -1110,7 +1110,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         // matrix reads walk the skewed storage with cursors instead of index arithmetic per step.  Values are those of the general
         // loop below: candidates that are switched off there (no left / diagonal neighbour, top row) are -infinity, `lik_insert`
         // or `0 + x` here, which lose to the floors exactly where the reference's never-assigned candidates do.
-        if (G < 64 && J.K <= 0 && __ballot(mine && state < 0) == 0ull) {
+        const bool use_f = mine && c == 0 && sidx > 0;          // lane 0 reads the spliced forward column
+        const bool use_b = is_t && backind > 0;                  // the target lane reads the backward column
+        // (a lane that reads both — an edit so close to the end of the sequence that its only new column is the target — takes the general loop)
+        if (G < 64 && J.K <= 0 && __ballot((mine && state < 0) || (use_f && use_b)) == 0ull) {
             // (column-sparse records, J.K < 0: a column is one contiguous run of records, the cursors move by one; the wrap tests
             //  of the skewed storage never fire)
             const bool sp = J.K < 0;
@@ -1120,8 +1123,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             const double2* __restrict__ rb = b.rec + J.mat_off[1];
             const double NINF = -__builtin_inf();
             int i = base - 1 - c;                                    // row of this lane on step t = -1
-            const bool use_f = mine && c == 0 && sidx > 0;          // lane 0 reads the spliced forward column
-            const bool use_b = is_t && backind > 0;                  // the target lane reads the backward column
             int fslot = i >= 0 ? i % P : 0, bslot = (n0 - i + 1) % P;
             unsigned fidx = (unsigned)(max(i, 0) + sidx) * (unsigned)P + (unsigned)fslot;            // record of (i, sidx), forward matrix
             unsigned bidx = (unsigned)(n0 - i + 1 + backind) * (unsigned)P + (unsigned)bslot;        // record of (n0 - i + 1, backind), backward matrix
@@ -1130,15 +1131,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 fidx = use_f ? (unsigned)J.keep[0][sidx] * (unsigned)J.pitch + (unsigned)(i - pc0) : 0u;
                 bidx = use_b ? (unsigned)J.keep[1][backind] * (unsigned)J.pitch + (unsigned)(n0 - i + 1 - bb0) : 0u;
             }
+            // one cursor per lane: a lane reads the forward column (lane 0 of an item, `use_f`) or the backward one (the target lane,
+            // `use_b`: new column len(mut) + 4 of the edit unless the sequence ends before) — not both (checked above)
+            const bool bwd = use_b;
+            unsigned idx = bwd ? bidx : fidx;
+            int slot = bwd ? bslot : fslot;
+            const int sgn = bwd ? -1 : 1, wrap_at = bwd ? 0 : P - 1, wrap_to = bwd ? P - 1 : 0;
+            const unsigned dstride = bwd ? 0u - stride : stride;
             const double log2pi = b.log2pi, off = J.lik_offset;
+            // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}; scalar base + unsigned 32-bit byte offset: one vector
+            // instruction of address arithmetic.  (Fetched a step ahead it was 4 % slower, and the band masks as one high-word select
+            // in front of a bare v_max_f64 9 % slower, than this loop: measured, `tools/gpu_scorebench.py`.)
+            auto level_of = [&](int row) { return *(const PS_GLOBAL v4d*)((const PS_GLOBAL char*)levf + (unsigned)(32 * (clampi(row, 1, n0) - 1))); };
             for (int t = -1; t <= span; t++) {
+                const v4d lv4 = level_of(i);
                 double L = wave_shr1(cm);
                 const bool vl = i >= p0 && i <= p1;
-                if (c == 0) { L = 0.0; if (use_f && vl && i >= 1) L = rf[fidx].x; }
+                if (c == 0) { L = 0.0; if (use_f && vl && i >= 1) L = rf[idx].x; }
                 const double D = lprev;
                 lprev = L;
                 const bool inb = mine && i >= i0 && i <= i1;
-                const v4d lv4 = levf[clampi(i, 1, n0) - 1];          // forward level record of row i: {mean, stdv, 3 log stdv, 1 / stdv}
                 const double lev[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
                 const double o = emission8<FD>(mr, lev, log2pi, off);
                 const bool vd = vl && i != p0, top = i == i0;
@@ -1157,15 +1169,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 const int jb = n0 - i + 1;
                 const bool hit = inb && is_t && jb >= bb0 && jb <= bb1;
                 double2 bv = make_double2(0.0, 0.0);
-                if (hit && use_b) bv = rb[bidx];
+                if (hit && use_b) bv = rb[idx];
                 const double cand = fmax(nm + bv.x, ns + bv.y);
                 tm = hit ? fmax(tm, cand) : tm;
                 // next row: one anti-diagonal on, one slot on (forward); one back each (backward)
                 i++;
-                const bool fw = fslot + 1 == P;
-                fidx += fw ? 1u : stride; fslot = fw ? 0 : fslot + 1;
-                const bool bw = bslot == 0;
-                bidx -= bw ? 1u : stride; bslot = bw ? P - 1 : bslot - 1;
+                const bool wr = slot == wrap_at;
+                idx += wr ? (unsigned)sgn : dstride; slot = wr ? wrap_to : slot + sgn;
             }
         } else {
             for (int t = -1; t <= span; t++) {

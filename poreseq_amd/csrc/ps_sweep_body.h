@@ -39,15 +39,6 @@ __device__ __forceinline__ double wave_ror1(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// `x` where keep, else a huge negative FINITE number: only the high word is selected (0xFFEFFFFF: -1.797e308 whatever the low word
-// holds).  It stands for "no cell here" exactly as -infinity does — it loses every maximum against a real score (>= 0), against the
-// floors 0 and -1e300 and in every `>` test, adding an emission or a transition term leaves it where it is, and two of them are never
-// added — at one v_cndmask instead of two.
-__device__ __forceinline__ double keep_or_absent(double x, bool keep) {
-    const int hi = keep ? __double2hiint(x) : (int)0xFFEFFFFF;
-    return __hiloint2double(hi, __double2loint(x));
-}
-
 // columns of the LDS ring of per-column maxima: the widest window (NL - 1 strips) + the 64 steps between two flushes, rounded up
 __host__ __device__ constexpr int ring_cols(int nw) { return nw <= 2 ? 256 : 512; }
 constexpr int HAND_DOUBLES = 4;   // LDS hand-off record of a wave's last lane: {main, stay (+ emission), main + emission, -}
