@@ -836,9 +836,9 @@ void sweep_form_set(int K, int NW) { g_form_K.store(K); g_form_NW.store(NW); }
 static SweepForm pick_form(int W, int nsweeps, bool fastdiv) {
     SweepForm f;
     int fk = g_form_K.load(), fnw = g_form_NW.load();
-    if (fk <= 0) {
+    if (fk <= 0 && fnw <= 0) {                                    // (the API has precedence: the environment speaks only when neither was set)
         static const char* e = getenv("PORESEQ_SWEEP_FORM");
-        if (e && sscanf(e, "%d,%d", &fk, &fnw) != 2) fk = 0;
+        if (e && sscanf(e, "%d,%d", &fk, &fnw) != 2) { fk = 0; fnw = 0; }
     }
     if (fk > 0 && sweep_form_exists(fk, fnw) && (fnw == 1 || fastdiv)) { f.K = fk; f.NW = fnw; return f; }
     if (fk <= 0 && (fnw == 1 || fnw == 2 || fnw == 4)) {         // only the wavefronts per sweep are given: the smallest strip height that fits

@@ -15,8 +15,10 @@ def init(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("PORESEQ_DEVICE", str(local))   # read by libporeseq_hip when it first touches the GPU
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    # ONE mapping of local ranks to devices, shared by the library (PORESEQ_DEVICE, read when it first touches the GPU), the device
+    # fraction below and torch's current device: local rank r runs on device r mod (devices of the node)
+    os.environ.setdefault("PORESEQ_DEVICE", str(_device_of(local)))
     _pin_host_cores(local, local_world)
     _share_device(local, local_world)
     force = os.environ.get("PORESEQ_FORCE_PG") == "1"     # tests: exercise the collective path on one GPU
@@ -24,25 +26,53 @@ def init(backend=None):
         if backend is None:
             backend = os.environ.get("PORESEQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+            torch.cuda.set_device(_device_of(local))
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        global _ATEXIT
+        if not _ATEXIT:
+            import atexit
+            atexit.register(_leave_quietly)
+            _ATEXIT = True
     return rank, local, world
+
+
+_ATEXIT = False
+
+
+def _leave_quietly():
+    """atexit: a script that ends without finalize() still tears its process group down (a process that exits with the group's
+    worker threads alive ends in std::terminate -> SIGABRT).  No barrier here: a peer that has crashed must not hang the others'
+    exit; the drivers themselves end with one (_gather_and_meet)."""
+    try:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def _ndev():
+    try:
+        return int(torch.cuda.device_count())        # (counts devices without initialising the GPU)
+    except Exception:
+        return 0
+
+
+def _device_of(local):
+    """device index of local rank `local`: local mod the node's device count (0 without a GPU)"""
+    return int(local) % max(1, _ndev())
 
 
 def _share_device(local, local_world):
     """More local ranks than GPUs (tests of the N-rank command line on one device; never the production layout): every rank plans its
     device memory — slabs, runtime shares, pool ceiling — for its fraction of the device it lands on (include/poreseq_hip.h,
     ps_set_device_fraction), through the environment because the library reads it at its first compute call."""
-    try:
-        ndev = torch.cuda.device_count()             # (counts devices without initialising the GPU)
-    except Exception:
-        ndev = 0
+    ndev = _ndev()
     if ndev < 1 or local_world <= ndev:
         return 1.0
-    mine = sum(1 for r in range(local_world) if r % ndev == local % ndev)
+    mine = sum(1 for r in range(local_world) if _device_of(r) == _device_of(local))
     frac = 1.0 / max(1, mine)
     os.environ.setdefault("PORESEQ_DEVICE_FRACTION", "%.6f" % frac)
     return frac
@@ -123,15 +153,19 @@ def gather_regions(local_results, n_regions, max_events):
     maxlen = max([len(s) for _, s, _ in local_results] + [0])
     maxlen = int(max_over_ranks(maxlen))
     dev = device()
-    seqs = torch.zeros((per, maxlen + 1), dtype=torch.uint8, device=dev)
-    meta = torch.full((per, 2), -1, dtype=torch.int64, device=dev)
-    scores = torch.zeros((per, max_events), dtype=torch.float64, device=dev)
+    # built on the host, one copy per tensor to the device (under nccl: three H2D copies per rank, not three per region)
+    h_seqs = np.zeros((per, maxlen + 1), dtype=np.uint8)
+    h_meta = np.full((per, 2), -1, dtype=np.int64)
+    h_scores = np.zeros((per, max_events), dtype=np.float64)
     for k, (idx, s, sc) in enumerate(local_results):
         b = np.frombuffer(s.encode("ascii"), dtype=np.uint8)
-        seqs[k, :len(b)] = torch.from_numpy(b.copy()).to(dev)
-        meta[k, 0], meta[k, 1] = idx, len(b)
+        h_seqs[k, :len(b)] = b
+        h_meta[k, 0], h_meta[k, 1] = idx, len(b)
         sc = np.asarray(sc, dtype=np.float64)
-        scores[k, :len(sc)] = torch.from_numpy(sc).to(dev)
+        h_scores[k, :len(sc)] = sc
+    seqs = torch.from_numpy(h_seqs).to(dev)
+    meta = torch.from_numpy(h_meta).to(dev)
+    scores = torch.from_numpy(h_scores).to(dev)
     if world > 1:
         gs = [torch.empty_like(seqs) for _ in range(world)]
         gm = [torch.empty_like(meta) for _ in range(world)]
@@ -277,7 +311,16 @@ def run_regions(regions, process, max_events=64, in_flight=1, fresh_rand=_fresh_
             local = list(pool.map(one, mine))
     else:
         local = [one(it) for it in mine]
-    return gather_regions(local, len(regions), max_events)
+    return _gather_and_meet(local, len(regions), max_events)
+
+
+def _gather_and_meet(local, n_regions, max_events):
+    """the final gather, then a barrier: every rank holds every result before any rank returns, so a driver script that ends right
+    behind its call (cmdline.py:182-195: the reference's region processes exit independently) cannot tear down connections a slower
+    peer is still receiving on"""
+    got = gather_regions(local, n_regions, max_events)
+    barrier()
+    return got
 
 
 def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_events=64, in_flight=1):
@@ -318,7 +361,7 @@ def refine_regions(regions, make_region_pa, params=None, batch=16, reps=4, max_e
         return [(idx, seq, np.array([acc])) for (idx, _), (seq, acc) in zip(chunk, res)]
 
     local = [r for part in stream_batches(chunks, one, in_flight, enter=_enter_hip_library if hip_backend else None) for r in part]
-    got = gather_regions(local, len(regions), max_events)
+    got = _gather_and_meet(local, len(regions), max_events)
     return [(s, float(c[0])) for s, c in got]
 
 

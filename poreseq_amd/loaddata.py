@@ -59,8 +59,12 @@ def events_from_bam_records(records, load_event, start, end, params):
                     ev.flip()
                 ev.mapaligns(aps)
                 events.append(ev)
-            except Exception:
-                pass
+            except ImportError:
+                raise                      # a missing reader module is not "a read without that strand"
+            except Exception as e:         # LoadData.py:146-147: the strand is skipped, the error shown
+                if params.get("verbose", 0):
+                    import sys
+                    sys.stderr.write("Skipping %s strand %s: %s\n" % (rec.query_name, loc, e))
     if not events:
         raise Exception("No aligned reads found!")
     return events
@@ -75,6 +79,10 @@ def events_from_bam(eventdir, bamfile, reginfo, params):
     except ImportError as e:
         raise ImportError("events_from_bam reads BAM files through pysam, which is not installed; "
                           "events_from_bam_records takes the parsed records") from e
+    try:
+        import h5py  # noqa: F401 — PSEvent.from_fast5 reads every strand through it: fail here, not once per strand
+    except ImportError as e:
+        raise ImportError("events_from_bam loads every strand with PSEvent.from_fast5, which needs h5py (not installed)") from e
     from .events import PSEvent
     bam = pysam.AlignmentFile(bamfile, "rb")
     if reginfo.name is None:

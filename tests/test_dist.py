@@ -35,6 +35,7 @@ t = psdist.max_over_ranks(rank + 1.5)
 psdist.barrier()
 if rank == 0:
     print(json.dumps({"world": world, "tmax": t, "seqs": [r[0] for r in res], "scores": [r[1][:3].tolist() for r in res]}))
+psdist.finalize()
 '''
 
 
@@ -103,6 +104,7 @@ res = psdist.refine_regions(regions, make, params=None, batch=2, reps=1)
 loads = psdist.max_over_ranks(sum(b - a for _, (a, b) in mine))
 if rank == 0:
     print(json.dumps({"world": world, "seqs": [r[0] for r in res], "accs": [r[1] for r in res], "maxload": loads}))
+psdist.finalize()
 '''
 
 
@@ -145,6 +147,7 @@ else:
     loads = [made]
 if rank == 0:
     print(json.dumps({"world": world, "seq": seq, "regions": [[a, b] for a, b, _, _ in parts], "accs": [p[3] for p in parts], "made": loads}))
+psdist.finalize()
 '''
 
 
@@ -167,6 +170,51 @@ def test_polish_six_regions_on_eight_ranks_equals_one_rank():
     assert sorted(len(m) for m in eight["made"]) == [0, 0, 1, 1, 1, 1, 1, 1]              # one region per rank, two ranks idle
     assert sorted(tuple(r) for m in eight["made"] for r in m) == [tuple(r) for r in sorted(eight["regions"])]   # every region built once
     assert "6 regions on 8 ranks: ranks [6, 7] idle" in out
+
+
+WORKER_SLOTS = r"""
+import copy, os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import backends as B
+from poreseq_amd import dist as psdist, synth
+from poreseq_amd.util import DEFAULT_PARAMS
+rank, local, world = psdist.init(backend="gloo")
+P = dict(DEFAULT_PARAMS, verbose=0)
+P.pop("end_trim")
+# nine ragged region work-items (a chromosome's short tail included)
+regions = [(0, 210), (210, 330), (330, 520), (520, 600), (600, 830), (830, 900), (900, 1100), (1100, 1150), (1150, 1390)]
+def make(a, b):
+    draft, events, truth = synth.make_region(b - a, 3, 1300 + a, B.oracle_swalign, P)
+    return B.make_pa(B.OraclePSAlign, draft, events, P)
+res = psdist.refine_regions(regions, make, params=None, batch=1, reps=1, in_flight=int(os.environ.get("TEST_IN_FLIGHT", "2")))
+if rank == 0:
+    print(json.dumps({"world": world, "seqs": [r[0] for r in res], "accs": [r[1] for r in res]}), flush=True)
+# NO finalize(): a driver script that simply ends behind refine_regions must not take its peers down (the call ends with a
+# barrier and the package tears the process group down at exit)
+"""
+
+
+def test_refine_regions_streaming_slots_world4_equals_world1_and_exits_cleanly():
+    """Nine ragged regions over four gloo ranks, two batch slots (host threads) per rank: the same sequences as one rank with one
+    slot — results do not depend on world size, in_flight or the slot — and every rank exits cleanly WITHOUT calling finalize()
+    (cmdline.py:182-195: the reference's region processes end independently; ours must not abort one another)."""
+    global WORKER
+    keep, WORKER = WORKER, WORKER_SLOTS
+    try:
+        os.environ["TEST_IN_FLIGHT"] = "1"
+        one = run_world(1)
+        os.environ["TEST_IN_FLIGHT"] = "2"
+        code = WORKER % {"root": ROOT}
+        out = _torchrun(code, 4, 29500 + (os.getpid() * 17 + 433) % 2000).decode()      # (raises on any rank's non-zero exit)
+    finally:
+        WORKER = keep
+        os.environ.pop("TEST_IN_FLIGHT", None)
+    import json
+    four = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert four["world"] == 4 and len(four["seqs"]) == 9
+    assert four["seqs"] == one["seqs"] and four["accs"] == one["accs"]
+    assert "terminate called" not in out and "SIGABRT" not in out
 
 
 def test_split_and_merge_regions():

@@ -209,3 +209,38 @@ def test_file_readers_say_which_library_is_missing(monkeypatch):
         PSEvent.from_fast5("x.fast5", "t")
     with pytest.raises(ImportError, match="pysam"):
         loaddata.events_from_bam(".", "x.bam", RegionInfo("0:10"), {})
+
+
+def test_missing_h5py_reaches_the_caller_not_no_reads_found(monkeypatch, capsys):
+    """with pysam present and h5py absent the promised ImportError must surface (before: swallowed per strand, the user
+    saw 'No aligned reads found!'); other per-strand failures are skipped and — under `verbose` — shown, as LoadData.py:146-147 does."""
+    import sys, types
+    from poreseq_amd.util import RegionInfo
+
+    class AlignmentFile:
+        nreferences, references = 1, ("chrT",)
+
+        def __init__(self, fn, mode):
+            pass
+
+        def fetch(self, reference=None, start=None, end=None):
+            return iter([])
+    monkeypatch.setitem(sys.modules, "pysam", types.SimpleNamespace(AlignmentFile=AlignmentFile))
+    monkeypatch.setitem(sys.modules, "h5py", None)
+    with pytest.raises(ImportError, match="h5py"):
+        loaddata.events_from_bam(".", "x.bam", RegionInfo("0:10"), {})
+    recs = [Rec(k) for k in range(len(Z["bam_rec_name"]))]
+    start, end = (int(x) for x in Z["bam_region"])
+    mo, mc, mn = (int(x) for x in Z["bam_params"])
+    params = {"min_overlap": mo, "max_coverage": mc, "min_coverage": mn, "verbose": 1}
+
+    def no_reader(name, loc):
+        raise ImportError("no h5py here")
+    with pytest.raises(ImportError, match="no h5py here"):
+        loaddata.events_from_bam_records(recs, no_reader, start, end, params)
+
+    def broken(name, loc):
+        raise KeyError("Basecall_2D_000")
+    with pytest.raises(Exception, match="No aligned reads found"):
+        loaddata.events_from_bam_records(recs, broken, start, end, params)
+    assert "Skipping" in capsys.readouterr().err

@@ -13,9 +13,9 @@ set -u
 cd "$GRAFT_REPO_ROOT"
 names=$1; shift
 lib=poreseq_amd/csrc/libporeseq_hip.so
-cp $lib /tmp/lib_keep.so
+cp $lib /tmp/lib_keep.so || exit 1
+trap 'cp /tmp/lib_keep.so "$lib"' EXIT      # an interrupt or a timeout must not leave a variant library installed
 for v in $names; do
   cp tools/_libs/lib_$v.so $lib || continue
   echo "variant $v: $("$@" 2>&1 | head -1)"
 done
-cp /tmp/lib_keep.so $lib
