@@ -2,6 +2,7 @@
 #include <cmath>
 
 #include "ps_host.h"
+#include "ps_sweep_body.h"   // layout and predicate bits of the strip sweeps' code bytes
 
 namespace ps {
 
@@ -35,7 +36,14 @@ int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* sta
     if (!K) PS_HIP(hipMemcpyAsync(flg.data(), b.d.flg + J.mat_off[dir], flg.size() * sizeof(unsigned short), hipMemcpyDeviceToHost, rt->stream));
     else PS_HIP(hipMemcpyAsync(codes.data(), b.sd.codes + sj0.codes_off, codes.size(), hipMemcpyDeviceToHost, rt->stream));
     PS_HIP(hipStreamSynchronize(rt->stream));
-    auto plane_sz = [](int rem) { return rem >= 16 ? 16 : rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1; };
+    auto band_of_col = [&](int c, int& i0, int& i1) {   // rows of column c (0: the blank column, all rows)
+        if (c < 1) { i0 = 0; i1 = n0; return; }
+        int ce;
+        if (dir == 0) { int v = lb[c]; ce = v < 0 ? 1 : v; }
+        else { int v = lb[C - c + 1]; ce = v < 0 ? 1 : n0 - v + 1; }
+        ce = std::min(std::max(ce, 1), n0);
+        i0 = std::max(1, ce - J.W); i1 = std::min(n0, ce + J.W);
+    };
     // column 0 is the blank column: rows 0..n0, all zero (cpp/Alignment.cpp:42-43)
     for (int i = 0; i <= n0; i++) { main[(size_t)i * ld] = 0.0; if (stay) stay[(size_t)i * ld] = 0.0; }
     if (o.inert) return PS_OK;
@@ -53,11 +61,12 @@ int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* sta
                 main[to] = rec[at].x;
                 if (stay) stay[to] = rec[at].y;
                 if (dir == 0 && (sm || ss)) {
-                    int r0 = 0, off = 0;
-                    for (;;) { const int sz = plane_sz(K - r0); if (r < r0 + sz) { off = NL * r0 + (q & (NL - 1)) * sz + (r - r0); break; } r0 += sz; }
-                    const unsigned by = codes[(size_t)(c + q) * NL * K + off];
-                    if (sm) sm[to] = (uint8_t)((by & 7) == 7 ? 255 : (by & 7));
-                    if (ss) ss[to] = (uint8_t)(((by >> 3) & 3) ? 3 + ((by >> 3) & 3) : 0);
+                    // raw predicate byte -> the reference's step codes (ps_sweep_body.h); a column without a 5-mer has no steps
+                    const unsigned by = a->states[c - 1] < 0 ? 0u : code_fetch(codes.data() + (size_t)(c + q) * NL * K, K, q & (NL - 1), r, NL);
+                    int p0, p1;
+                    band_of_col(c - 1, p0, p1);
+                    if (sm) sm[to] = (uint8_t)code_main_step(by, i > p0 && i <= p1);
+                    if (ss) ss[to] = (uint8_t)code_stay_step(by);
                 }
                 continue;
             }

@@ -12,6 +12,16 @@ enum : unsigned { M_SKIP = 0, M_MATCH = 1, M_INSERT = 2, M_IGNORE = 3, M_STAY = 
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Short serial kernels of a launch chain (walkers, table builders: < 3 % of the vector work, a fifth of a ScoreMutations chain's
+// latency under load) raise their waves' issue priority at entry: beside three sweep waves on its SIMD a lone walker wave otherwise
+// gets a quarter of the issue slots and runs 4x slower than alone, while its batch offers the chip nothing else.
+#ifndef PS_WALKER_PRIO
+#define PS_WALKER_PRIO 3
+#endif
+__device__ __forceinline__ void chain_priority() {
+    if (PS_WALKER_PRIO > 0) __builtin_amdgcn_s_setprio(PS_WALKER_PRIO);
+}
+
 // std::lower_bound(double*, int) exactly as libstdc++ walks it (cpp/EventData.h:178)
 __device__ inline int lower_bound_d(const double* __restrict__ a, int n, int v) {
     int first = 0, len = n;

@@ -33,6 +33,7 @@ namespace ps {
 // column C + 1 an empty sentinel.  grid (ceil((maxC + 2) / 256), njobs)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_band(BatchD b, SweepD sw) {
+    chain_priority();
     const int jd = blockIdx.y, dir = jd % sw.ndir;
     const JobD& J = b.jobs[jd / sw.ndir];
     const SweepJob& SJ = sw.sj[jd];
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void k_band(BatchD b, SweepD sw) {
 // Strip q works on column t - q; it is in band iff  i0(t-q) <= qK + K  (true from some q on: i0 falls as the column does)
 // and  i1(t-q) >= qK + 1  (true up to some q).  grid (ceil((maxT + Q_PAD) / 256), njobs * ndir)
 __global__ __launch_bounds__(256) void k_qlo(BatchD b, SweepD sw) {
+    chain_priority();
     const int jd = blockIdx.y;
     const JobD& J = b.jobs[jd / sw.ndir];
     const SweepJob& SJ = sw.sj[jd];
@@ -115,6 +117,7 @@ void k_sweeps(BatchD b, SweepD sw) {
 // the global maximum and its first cell — smallest column, then smallest row (cpp/Alignment.cpp:158, 270: strict '>' over columns
 // in order, rows in order) — from the per-strip records; one wave per job
 __global__ __launch_bounds__(64) void k_best(BatchD b, SweepD sw) {
+    chain_priority();
     const JobD& J = b.jobs[blockIdx.x];
     JobOut* O = J.out;
     if (O->inert) return;
@@ -143,24 +146,37 @@ __global__ __launch_bounds__(64) void k_best(BatchD b, SweepD sw) {
 template <int K>
 struct StripCodes {
     const unsigned char* codes;
+    const int2* band;                       // the sweep's band table of the job (forward): band[j] = rows of column j, j = 0 .. C + 1
+    const int* st;                          // the sequence's 5-mers: a column without one has no cell
     int nl;                                 // lanes of a sweep (64 per wave): strip q sits on lane q mod nl
     static constexpr bool ROWFAST = true;   // consecutive threads take consecutive rows: K contiguous bytes per strip
     __device__ __forceinline__ void prep(int) {}
+    // the walker's step word of cell (row, column) from the sweep's raw predicate byte (ps_sweep_body.h, CB_*): the byte says which
+    // candidates equal the cell's score and which scores are positive; whether the cell exists (its column has a 5-mer and the row is
+    // in the column's band) and whether a MATCH is a real or an implicit one (cpp/Alignment.cpp:207-220: the diagonal neighbour in
+    // the previous column's band) are looked up here — 64 consecutive threads of a tile load share the column
     __device__ __forceinline__ unsigned short word(int ti, int tj, int a, int c) const {
         const int r = ti - a, col = tj - c;
         if (r < 1 || col < 1) return (unsigned short)0xC000u;   // outside the matrix: score 0, the walk stops
+        const int2 bc = band[col], bp = band[col - 1];
+        if (st[col - 1] < 0 || r < bc.x || r > bc.y) return (unsigned short)0xC000u;   // no cell here
         const int q = (r - 1) / K, rr = (r - 1) - q * K;
-        const unsigned by = codes[(size_t)(col + q) * (nl * K) + code_off<K>(q & (nl - 1), rr, nl)];
-        const unsigned sm = by & 7u, ss = (by >> 3) & 3u;
-        return (unsigned short)((sm == 7u ? (unsigned)M_IMPL : sm) | ((ss ? 3u + ss : 0u) << 8) | ((by & 0x60u) << 9));
+        const unsigned by = code_fetch(codes + (size_t)(col + q) * (nl * K), K, q & (nl - 1), rr, nl);
+        const bool vd = r > bp.x && r <= bp.y;
+        const unsigned sm = code_main_step(by, vd), ss = code_stay_step(by);
+        return (unsigned short)(sm | (ss << 8) | ((by & CB_POS) ? 0u : 0x4000u) | ((by & CB_SPOS) ? 0u : 0x8000u));
     }
 };
 
 template <int K>
 __global__ __launch_bounds__(256) void k_backtrace_s(BatchD b, SweepD sw) {
+    chain_priority();
     const JobD& J = b.jobs[blockIdx.x];
+    const SweepJob& SJ = sw.sj[blockIdx.x * sw.ndir];
     StripCodes<K> src;
-    src.codes = sw.codes + sw.sj[blockIdx.x * sw.ndir].codes_off;
+    src.codes = sw.codes + SJ.codes_off;
+    src.band = sw.band + SJ.band_off;
+    src.st = J.st;
     src.nl = sw.nl;
     bt_walk(J, src);
 }
@@ -186,6 +202,7 @@ __device__ __forceinline__ double cell_emission(const BatchD& b, const JobD& J, 
 
 template <bool FD>
 __global__ __launch_bounds__(256) void k_like_a(BatchD b) {
+    chain_priority();
     const JobD& J = b.jobs[blockIdx.y];
     if (J.out->inert) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(256) void k_like_a(BatchD b) {
 
 template <bool FD>
 __global__ __launch_bounds__(64) void k_like_b(BatchD b) {
+    chain_priority();
     const JobD& J = b.jobs[blockIdx.x];
     const JobOut O = *J.out;
     if (O.inert || O.bi <= 0) return;
@@ -245,6 +263,7 @@ __global__ __launch_bounds__(64) void k_like_b(BatchD b) {
 // ------------------------------------------------------------------------------------------------
 constexpr int LK_MAXC = 12 * 1024;      // bases per sequence the LDS index table holds (longer sequences take the host loop)
 __global__ __launch_bounds__(256) void k_likes(BatchD b, const LikeGroup* __restrict__ groups, double* __restrict__ out) {
+    chain_priority();
     __shared__ int s_idx[LK_MAXC];
     __shared__ int s_part[256];
     const LikeGroup G = groups[blockIdx.x];

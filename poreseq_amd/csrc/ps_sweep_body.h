@@ -12,20 +12,63 @@
 
 namespace ps {
 
-// ---- byte layout of one step's codes: row groups ("planes") of 16 / 8 / 4 / 2 / 1 rows, each [NL lanes][rows of the group] ----
+// ---- layout of one step's codes: row groups ("planes") of 16 / 8 / 4 / 2 / 1 rows, each [NL lanes][bytes of the group], one byte per
+// row.  A lane builds the codes of up to four consecutive rows in ONE register by shifting predicate bits in at the bottom (code_push),
+// CODE_BITS per row: the first row of a register sits in its highest field.  So a plane of four or more rows is 32-bit words of four
+// 7-bit fields (row 4w + k of the plane in bits 7 (3 - k) .. of word w), a plane of two rows a 16-bit word of two, a plane of one a byte.
+constexpr int CODE_BITS = 7;
 __host__ __device__ constexpr int plane_sz(int rem) { return rem >= 16 ? 16 : rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1; }
-template <int K>
-__device__ __forceinline__ int code_off(int lane, int r, int nl) {
+// the code of row r (0 .. K - 1) of a lane's strip in the bytes of one step (`step` = the step's first byte, NL K bytes)
+__host__ __device__ inline unsigned code_fetch(const unsigned char* step, int K, int lane, int r, int nl) {
     int r0 = 0;
-#pragma unroll
-    for (int g = 0; g < 8; g++) {
+    for (;;) {
         const int sz = plane_sz(K - r0);
-        if (r < r0 + sz) return nl * r0 + lane * sz + (r - r0);
+        if (r < r0 + sz) {
+            const int rr = r - r0;
+            const unsigned char* p = step + nl * r0 + lane * sz;
+            if (sz >= 4) return (*(const unsigned*)(p + (rr & ~3)) >> (CODE_BITS * (3 - (rr & 3)))) & 0x7Fu;
+            if (sz == 2) return ((unsigned)*(const unsigned short*)p >> (CODE_BITS * (1 - rr))) & 0x7Fu;
+            return (unsigned)*p & 0x7Fu;
+        }
         r0 += sz;
-        if (r0 >= K) break;
     }
-    return 0;
 }
+
+// ---- one cell's code: seven raw predicate bits of the fill (cpp/Alignment.cpp:196-267), decoded by the few readers ----
+// The sweep does not work the reference's step codes out per cell (a chain of nine selects and four shifts / ors per cell, a fifth of
+// a forward cell's vector instructions for a byte the backtrace reads on ~10 000 of 6 000 000 cells): every bit is ONE compare whose
+// lane mask goes from its scalar register pair straight into the byte as the carry of an add-with-carry.  The reader combines them
+// with what it can look up itself: whether the cell is in its column's band (act), whether the diagonal neighbour is in the
+// previous column's band (vd: MATCH against implicit MATCH, cpp/Alignment.cpp:207-220) and whether the column has a 5-mer.
+enum : unsigned { CB_POS = 1u,     // main score > 0
+                  CB_IGN = 2u, CB_INS = 4u, CB_MATCH = 8u, CB_SKIP = 16u,   // candidate == the cell's main score; the first in the reference's order SKIP, MATCH, INSERT, IGNORE wins, none: STAY
+                  CB_SPOS = 32u,   // stay score > 0
+                  CB_EXT = 64u };  // EXTEND > max(floor, STAY)  (strict: the stay matrix takes EXTEND)
+// ("STAY > floor" needs no bit: where the stay score is positive and EXTEND did not take it, STAY did — the floor of a row that has an
+//  upper neighbour is 0; where it is not positive neither candidate beat the floor: a first row's -1e300 loses to nothing its candidates
+//  can be, which are built on the absent-cell value — and the reference's step stays 0)
+// main step (0 SKIP, 1 MATCH, 2 INSERT, 3 IGNORE, 4 STAY, 255 implicit MATCH; 0 when the score is not positive) and stay step (0, 4 STAY, 5 EXTEND)
+__host__ __device__ inline unsigned code_main_step(unsigned by, bool vd) {
+    if (!(by & CB_POS)) return 0u;
+    return (by & CB_SKIP) ? 0u : (by & CB_MATCH) ? (vd ? 1u : 255u) : (by & CB_INS) ? 2u : (by & CB_IGN) ? 3u : 4u;
+}
+__host__ __device__ inline unsigned code_stay_step(unsigned by) { return (by & CB_EXT) ? 5u : (by & CB_SPOS) ? 4u : 0u; }
+
+#ifdef __HIPCC__
+// w = 2 w + (the lane's bit of a compare): the compare's lane mask is consumed where v_cmp left it (a scalar register pair)
+__device__ __forceinline__ unsigned code_push(unsigned w, bool c) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(w), "=s"(carry_out) : "v"(w), "s"(m));
+    return w;
+}
+__device__ __forceinline__ unsigned code_first(bool c) {     // the first bit of a register
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+    unsigned w;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(w) : "s"(m));
+    return w;
+}
+#endif
 
 struct StripBest { double v; int i, j; };
 constexpr int Q_PAD = 8;          // qlo entries behind T (all -1): the sweep looks three steps ahead
@@ -80,7 +123,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     const double NINF = -__builtin_inf();
 
     // ---- what a lane fetches ahead of the step it is needed on
-    struct Ahead { v4i bd; int sp, sc, kc; };   // bd = {p0, p1, i0, i1} of columns j - 1, j; sp / sc = 5-mer of column j - 1 / j; kc: kept-column index (MODE 2)
+    struct Ahead { int p1, i0, i1, sc, kc; };   // last band row of column j - 1, band rows and 5-mer of the lane's column j; kc: kept-column index (MODE 2)
     gcip keep = (gcip)uni_ptr(J.keep[DIR]);
     const int pitch = uni(J.pitch);
     // (every per-lane address below is a wave-uniform base in scalar registers + an unsigned 32-bit byte offset: the `saddr` form of
@@ -93,15 +136,14 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         const int q = ql + ((lane - ql) & (NL - 1));
         const int j = clampi(tt - q, 1, max(C, 1));   // (a sequence without a 5-mer has no live step; its prefetches still need an address)
         Ahead a;
-        a.bd = *(const PS_GLOBAL v4i_a4*)(band_c + (unsigned)(8 * (j - 1)));
-        typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));
-        if (DIR == 0) {
-            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st_c + (unsigned)(4 * (j - 1)));   // (ints of -1 around the list: column 0 reads as invalid)
-            a.sp = s2.x; a.sc = s2.y;
-        } else {                                                          // backward column j holds states[C - j]
-            const v2i_a4 s2 = *(const PS_GLOBAL v2i_a4*)(st_c + (unsigned)(4 * (C - j)));
-            a.sc = s2.x; a.sp = s2.y;
-        }
+        // {last row of column j - 1's band, first and last row of column j's}: three consecutive ints of the band table.  (The
+        // 16-byte load of both columns' bands had a dead component, whose register the compiler reused while the load was in flight —
+        // at the price of a full s_waitcnt vmcnt(0) in front of the reuse.)
+        typedef int v3i_a4 __attribute__((ext_vector_type(3), aligned(4)));
+        const v3i_a4 b3 = *(const PS_GLOBAL v3i_a4*)(band_c + (unsigned)(8 * j - 4));
+        a.p1 = b3.x; a.i0 = b3.y; a.i1 = b3.z;
+        // (forward column j holds states[j - 1], backward column j states[C - j]; ints of -1 around the list)
+        a.sc = *(const PS_GLOBAL int*)(st_c + (unsigned)(4 * (DIR == 0 ? j : C - j)));
         a.kc = MODE == 2 ? *(const PS_GLOBAL int*)(keep_c + (unsigned)(4 * j)) : -1;
         return a;
     };
@@ -188,10 +230,14 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                 *(PS_GLOBAL v2i*)p = v;
             } else if (sz == 4) {
                 *(PS_GLOBAL unsigned*)p = cw[r0 / 4];
-            } else if (sz == 2) {
-                *(PS_GLOBAL unsigned short*)p = (unsigned short)(cw[r0 / 4] >> (8 * (r0 & 3)));
             } else {
-                *p = (unsigned char)(cw[r0 / 4] >> (8 * (r0 & 3)));
+                // a register with nrow < 4 rows holds its first row in field nrow - 1: the plane's rows r0 .. r0 + sz - 1 are the sz
+                // fields from field nrow - (r0 mod 4) - sz on, last row lowest
+                const int nrow = K - (r0 & ~3) < 4 ? K - (r0 & ~3) : 4;
+                const int sh = CODE_BITS * (nrow - (r0 & 3) - sz);
+                // (the bits above the plane's fields are a neighbouring plane's or zero: the reader masks its field)
+                if (sz == 2) *(PS_GLOBAL unsigned short*)p = (unsigned short)(cw[r0 / 4] >> sh);
+                else *p = (unsigned char)(cw[r0 / 4] >> sh);
             }
             r0 += sz;
             if (r0 >= K) break;
@@ -256,9 +302,11 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         if ((PS_SWEEP_STRAIGHT && MODE != 1) || live) {   // (MODE 1 stores a record per cell and step: behind T - 1 there is no room for them)
             const int base = q * K + 1;
             const bool valid = live && j >= 1 && j <= C && a0.sc >= 0;     // (a column whose 5-mer is invalid is all zero: no cell takes part, cpp/Alignment.cpp:162-163)
-            const int ra = valid ? a0.bd.z - base : K, rb = valid ? a0.bd.w - base : -1;   // band rows relative to the strip
-            const int rc = a0.bd.x - base, rd_ = a0.bd.y - base;                          // previous column's band
-            const bool pzero = a0.sp < 0;                            // previous column invalid (or column 0): its scores read as zero
+            const int ra = valid ? a0.i0 - base : K, rb = valid ? a0.i1 - base : -1;   // band rows relative to the strip
+            // (of the previous column's band only the last row is looked at: a cell tells "diagonal neighbour in the previous column's
+            //  band" from the neighbour's value but for that row, below; the reader of the step codes looks the band up for MATCH
+            //  against implicit MATCH)
+            const int rp = a0.p1 - base;
             double um = wave_ror1(bot_m), us = wave_ror1(bot_s), ue = DIR ? wave_ror1(bot_e) : 0.0;
             if (NW > 1) { um = l0 ? hm : um; us = l0 ? hs : us; if (DIR) ue = l0 ? he : ue; }
             double dprev = dm, deprev = de;
@@ -274,33 +322,53 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                 // records of the lane's column: row i of the band [i0, i1] at REC[kc][i - i0]; recp = the strip's first row
                 // (offsets from K - 1 records in front of the pool's first column, where its padding starts: never negative for a strip
                 //  that meets the band; kept columns of one direction of one job: < 2^31 bytes)
-                const unsigned ro = (unsigned)((a0.kc * pitch + (base - a0.bd.z) + (K - 1)) * 16);
+                const unsigned ro = (unsigned)((a0.kc * pitch + (base - a0.i0) + (K - 1)) * 16);
                 recp = rec - 16 * (K - 1) + ro;
                 if (DEFER_REC) { poff = ro; pkept = kstore; }
                 if (kept && !valid)   // a kept column without a 5-mer: its band reads as zeros (cpp/Alignment.cpp:162-163)
-                    for (int r = max(0, a0.bd.z - base); r <= min(K - 1, a0.bd.w - base); r++) *(PS_GLOBAL v2d*)(recp + (size_t)r * 16) = (v2d){0.0, 0.0};
+                    for (int r = max(0, a0.i0 - base); r <= min(K - 1, a0.i1 - base); r++) *(PS_GLOBAL v2d*)(recp + (size_t)r * 16) = (v2d){0.0, 0.0};
             }
+            unsigned cw = 0u;                                        // code bytes of up to four rows, the first row's on top (code_push)
 #pragma unroll
             for (int r = 0; r < K; r++) {
                 const double o = ov[r];
                 const bool act = r >= ra && r <= rb;
                 const bool top = r == ra;
-                const bool vd = r > rc && r <= rd_;                  // cpp/Alignment.cpp:207: p0 < i <= p1
-                const bool rd = vd && !pzero;
+                // in band and not the band's first row (the compare of the row above serves: one per step more, none per cell)
+                const bool below = r - 1 >= ra && r <= rb;
                 const double pmr = pm[r];
                 double L;
                 asm("v_max_f64 %0, %1, 0" : "=v"(L) : "v"(pmr));
-                const double D = rd ? dprev : 0.0;
+                // The diagonal neighbour (row i - 1 of the previous column) takes part when p0 < i <= p1, the previous column's band
+                // (cpp/Alignment.cpp:207), else an implicit zero does.  A cell in band holds a main score >= 0 (every maximum starts from
+                // 0); a row outside the band — or a whole column without a 5-mer, or the blank column — the absent-cell value, hugely
+                // negative: that covers i - 1 < p0 and i - 1 > p1 by the neighbour's value alone.  Left is i = p1 + 1, whose neighbour
+                // (the last row of the previous band) holds a score the reference does not use: one integer compare per cell (`blank`)
+                // and one select of the high word make that neighbour absent too.
+                //   forward   MATCH = diagonal + emission, implicit: the emission alone -> one maximum of the neighbour with 0 gives either
+                //             (as for the left neighbour above); IGNORE = diagonal + lik_insert, implicit: the initial 0.0, which never wins
+                //             the strict '>' against the floor 0 and never equals a positive maximum — the absent value + lik_insert does neither
+                //   backward  (cpp/Alignment.cpp:384-394) MATCH = the neighbour's (main + emission), implicit: 0 — neutral beside the floor 0
+                //             of the same maximum, as anything negative is: no step codes are made backward, only the values count
+                const bool blank = rp == r - 1;
+                const double dq = __hiloint2double(blank ? (int)0xFFEFFFFF : __double2hiint(dprev), __double2loint(dprev));
+                double D = dq;
+                if (DIR == 0) asm("v_max_f64 %0, %1, 0" : "=v"(D) : "v"(dq));
+                const double eq_ = DIR ? __hiloint2double(blank ? (int)0xFFEFFFFF : __double2hiint(deprev), __double2loint(deprev)) : 0.0;
                 const double cSTAY = DIR == 0 ? um + o + lst : ue + lst;      // backward: (main + emission) of the cell above
                 const double cEXT = DIR == 0 ? us + o + lex : us + lex;       // backward: `us` carries stay + emission
                 const double cINS = um + lin;
                 const double cSKIP = L + lsk;
-                const double cMATCH = DIR == 0 ? D + o : (rd ? deprev : 0.0);
-                const double cIGN = D + lin;
-                // the stay floor of a band's first row is -1e300 (cpp/Alignment.cpp:230): a value that only ever loses.  Where the record of
-                // the cell is kept for a bit-exact comparison (MODE 1) it is -BIG itself; elsewhere -1e300 with a zero low word does
-                // the same at one select (the high word) instead of two
-                const double floor_s = MODE == 1 ? (top ? -BIG : 0.0) : __hiloint2double(top ? __double2hiint(-BIG) : 0, 0);
+                const double cMATCH = DIR == 0 ? D + o : eq_;
+                const double cIGN = dq + lin;
+                // The stay floor of a band's first row is -1e300 (cpp/Alignment.cpp:230): a value that only ever loses; the other rows' is 0.
+                // A first row has no upper neighbour in band: its STAY and EXTEND are built on the absent-cell value and lose to either
+                // floor, so its stay score is the floor itself and its main score does not depend on which.  Where the records are kept
+                // for a bit-exact comparison (MODE 1) the floor is -BIG as in the reference; elsewhere every row's floor is 0 and the first
+                // row's stay score leaves the cell as the absent-cell value instead (`below`, next to the band mask): to the row below
+                // and to columnMax (cpp/Alignment.h:181-214: stay + stay) it is the same "only ever loses" — one compare and one select
+                // per cell less.
+                const double floor_s = MODE == 1 ? (top ? -BIG : 0.0) : 0.0;
                 const double t1 = fmax(floor_s, cSTAY);
                 const double ns = fmax(t1, cEXT);
                 double nm = fmax(0.0, cSKIP);
@@ -308,27 +376,21 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                 nm = fmax(nm, cINS);
                 nm = fmax(nm, cIGN);
                 nm = fmax(nm, ns);
-                unsigned ss = 0u, sm = 4u;
                 if (DIR == 0) {
-                    // step codes: stay matrix STAY then EXTEND with strict '>', main matrix in the reference's order (first candidate equal to the maximum)
-                    const unsigned mcode = vd ? 1u : 7u;
-                    ss = cSTAY > floor_s ? 1u : 0u;
-                    ss = cEXT > t1 ? 2u : ss;
-                    sm = cIGN == nm ? 3u : sm;
-                    sm = cINS == nm ? 2u : sm;
-                    sm = cMATCH == nm ? mcode : sm;
-                    sm = cSKIP == nm ? 0u : sm;
-                    sm = nm > 0.0 ? sm : 0u;
+                    // the cell's code byte: stay matrix STAY then EXTEND with strict '>'; main matrix: which candidates equal the maximum (the
+                    // reader takes the first in the reference's order); the two "score > 0" bits the walker stops on.  A row outside the band
+                    // gets whatever its compares say: the reader knows the band.
+                    cw = (r & 3) == 0 ? code_first(cEXT > t1) : code_push(cw, cEXT > t1);
+                    cw = code_push(cw, ns > 0.0);
+                    cw = code_push(cw, cSKIP == nm);
+                    cw = code_push(cw, cMATCH == nm);
+                    cw = code_push(cw, cINS == nm);
+                    cw = code_push(cw, cIGN == nm);
+                    cw = code_push(cw, nm > 0.0);
+                    if ((r & 3) == 3 || r == K - 1) cwp[r >> 2] = cw;
                 }
-                // (a row outside the band carries both "score <= 0" bits — the walker stops there before it reads the step — as its scores
-                //  are the absent-cell value: `masked score > 0` = in band and `score > 0`, the mask joined in scalar registers)
-                const bool mpos = act && nm > 0.0, spos = act && ns > 0.0;
-                const double nmx = keep_or_absent(nm, act), nsx = keep_or_absent(ns, act);
-                if (DIR == 0) {
-                    unsigned w = sm | (ss << 3) | (mpos ? 0u : 32u) | (spos ? 0u : 64u);   // (every constant an inline operand; the step bits of a row outside the band are whatever the selects left)
-                    asm volatile("" : "+v"(w));                      // keep the byte's shift out of the selects' constants (a VGPR per shifted literal otherwise)
-                    if ((r & 3) == 0) cwp[r >> 2] = w; else cwp[r >> 2] |= w << (8 * (r & 3));
-                }
+                // (a row outside the band carries the absent-cell value in both matrices)
+                const double nmx = keep_or_absent(nm, act), nsx = keep_or_absent(ns, MODE == 1 ? act : below);
                 dprev = pmr;
                 pm[r] = nmx;
                 if (DIR) { deprev = pe[r]; pe[r] = nmx + o; }

@@ -145,3 +145,37 @@ def test_windows_that_leave_one_lane_idle_match_the_oracle():
     wins = {(int(k), int(n), int(w)) for k, n, w in re.findall(r"K = (\d+) on (\d) wavefronts, widest window (\d+) strips", r.stderr)}
     assert (4, 1, 63) in wins and (4, 2, 127) in wins and (2, 4, 255) in wins, sorted(wins)   # the windows that use every lane but one did occur
     assert any(k > 4 for k, n, w in wins)                                      # and wider ones took the next strip height
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw,K", [(1, 4), (2, 4), (4, 2), (2, 5), (4, 3), (1, 6)])
+def test_sweep_matrices_where_the_band_shifts_every_column(nw, K):
+    """Narrow bands (realign_width 33 and 61 on 260 / 400 bases: the band moves down on three columns of four) through the strip sweeps with
+    full records: forward and backward main / stay matrices and the step codes decoded from the sweeps' predicate bits equal the oracle's cell
+    for cell.  The cell below the previous column's last band row (i = p1 + 1) is the one the reference treats as an implicit start although
+    its diagonal neighbour holds a score (cpp/Alignment.cpp:207: p0 < i <= p1) — every shifting column has one, in both directions; strip
+    heights with planes of 4, 4 + 1, 2, 2 + 1 and 4 + 2 rows cover every layout of the code fields.  The launch counters prove that sweeps ran."""
+    import copy
+    import numpy as np
+    import backends as B
+    from poreseq_amd import synth, _capi
+    from poreseq_amd.util import DEFAULT_PARAMS
+    hip, orc = _capi.load_hip(), B.oracle_api()
+    hip.set_sweep_min(0); hip.set_sweep2_min(0); hip.set_sparse_min(0); hip.set_sweep_form(K, nw)
+    try:
+        for L, W, seed in ((260, 33, 13), (400, 61, 14)):
+            P = dict(DEFAULT_PARAMS, verbose=0, realign_width=float(W))
+            draft, events, truth = synth.make_region(L, 3, seed, B.oracle_swalign, P)
+            hip.prof_reset(); hip.prof_enable(1)
+            for d in (0, 1):
+                out = []
+                for api in (hip, orc):
+                    h = api.align_create(draft, copy.deepcopy(events), P)
+                    out.append(api.debug_fill(h, 2, d, events[2].mean.size, len(draft) - 4))
+                    api.align_destroy(h)
+                for k in range(4 if d == 0 else 2):
+                    assert np.array_equal(out[0][k], out[1][k], equal_nan=True), (nw, K, W, d, k)
+            hip.prof_enable(0)
+            assert hip.prof_get("sweep")[1] == 2 and hip.prof_get("fill")[1] == 0
+    finally:
+        hip.set_sweep_min(-1); hip.set_sweep2_min(-1); hip.set_sparse_min(-1); hip.set_sweep_form(0, 0)

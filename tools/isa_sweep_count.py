@@ -44,13 +44,16 @@ for l in body:
     c = cls(op)
     if c:
         ins.append((op, c, t))
-best = (0, 0, 0)
+loops = []
 for i, (op, c, t) in enumerate(ins):
     if c == "branch":
         tgt = t.split()[-1]
-        if tgt in labels and labels[tgt] < i and i - labels[tgt] > best[0]:
-            best = (i - labels[tgt], labels[tgt], i)
-n, a, b = best
+        if tgt in labels and labels[tgt] < i and i - labels[tgt] > 300:
+            loops.append((i - labels[tgt], labels[tgt], i))
+# outermost loops only, longest first; "--loop N" picks the N-th (0: the forward sweep of a kept-column kernel, 1: its backward sweep)
+loops = sorted([l for l in loops if not any(o is not l and o[1] <= l[1] and l[2] <= o[2] for o in loops)], reverse=True)
+which = int(sys.argv[sys.argv.index("--loop") + 1]) if "--loop" in sys.argv else 0
+n, a, b = loops[which]
 loop = ins[a:b + 1]
 nb = sum(1 for op, c, t in loop if op == "s_barrier")
 steps = max(nb, 1)
