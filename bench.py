@@ -317,15 +317,18 @@ def main():
         # every step starts at a barrier: the job's time for a step is the slowest rank's, and the run's the sum of those
         # (max over ranks of the per-rank sums would be optimistic: the slowest rank may differ from step to step)
         dt, dt_res, last = 0.0, 0.0, None
+        first_of_step = []              # region 0 of every timed step: (sequence, accuracy)
         for regs in timed_regs:
             t, outs = run_steps([regs], timed=True)
             dt += psdist.max_over_ranks(t)
             dt_res += psdist.max_over_ranks(t - load_s[-1])
             last = outs[-1]
+            first_of_step.append(outs[-1][0])
         psdist.barrier()
     else:
         dt, outs = run_steps(timed_regs, timed=True)
         last = outs[-1]
+        first_of_step = [o[0] for o in outs]
         psdist.barrier()
         dt_res = psdist.max_over_ranks(dt - sum(load_s))
         dt = psdist.max_over_ranks(dt)
@@ -363,6 +366,30 @@ def main():
         a1 = in_slot(lambda: swalign(last[0][0], regions[-1][0][2])[0])
         out["accuracy"] = {"draft_percent": a0, "consensus_percent": a1}
         out.update(pre)
+        # ---- parity inside the run: region 0 of EVERY timed step against the digest the reference's own C++ produced for that region
+        #      (tests/golden/bench_regions.json, made by tests/golden/make_golden_bench.py: full schedule, fresh rand() stream) ----
+        try:
+            import hashlib
+            with open(os.path.join(ROOT, "tests", "golden", "bench_regions.json")) as fh:
+                gold = {(g["length"], g["events"], g["seed"]): g for g in json.load(fh)["regions"]}
+            checked, bad = 0, []
+            for k, (seq, acc) in enumerate(first_of_step):
+                seed = 1002 + (args.warmup + k) % nsets          # region 0 of the step's set on rank 0 (see `sets` above)
+                g = gold.get((args.length, args.events, seed))
+                if g is None:
+                    continue
+                checked += 1
+                if hashlib.sha256(seq.encode("ascii")).hexdigest() != g["sequence_sha256"] or len(seq) != g["sequence_len"]:
+                    bad.append(k)
+            out["parity_in_run"] = (checked > 0 and not bad) if checked else None
+            out["parity_in_run_detail"] = {"steps_checked": checked, "steps_timed": len(first_of_step), "mismatching_steps": bad,
+                                           "what": "SHA-256 of region 0's consensus sequence after the full schedule, every timed step, against "
+                                                   "the reference C++ (oracle/_ref) run on the same region: tests/golden/bench_regions.json"}
+            if bad:
+                sys.stderr.write("bench.py: PARITY FAILURE in timed steps %s\n" % bad)
+        except (OSError, ValueError, KeyError) as e:
+            out["parity_in_run"] = None
+            out["parity_in_run_detail"] = {"error": str(e)}
 
         sched = None
         if live_prof:
@@ -519,6 +546,29 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
             out["cpu_baseline"] = cpu
+        # ---- flat scalar duplicates of what bounds the path: the driver's record keeps scalar fields only ----
+        flat = {}
+        r = out.get("roofline") or {}
+        v = r.get("valu") or {}
+        flat["roofline.valu_busy_frac"] = v.get("busy_frac")
+        flat["roofline.lane_insts_per_band_cell"] = v.get("lane_insts_per_band_cell")
+        flat["roofline.fp64_frac"] = (r.get("fp64") or {}).get("frac")
+        flat["roofline.alone_frac"] = (r.get("one_batch_alone") or {}).get("frac")
+        flat["roofline.aggregate_frac"] = r.get("aggregate_frac")
+        flat["roofline.fill_classes_aggregate_frac"] = (r.get("fill_classes_aggregate") or {}).get("frac")
+        c = out.get("cpu_baseline") or {}
+        ns = out.get("north_star_1kb") or {}
+        flat["cpu_baseline.same_size_measured_kb_s"] = (c.get("measured_full_schedule_same_size") or {}).get("value")
+        flat["cpu_baseline.same_size_extrapolated_kb_s"] = (c.get("same_size") or {}).get("value")
+        flat["cpu_baseline.per_core_64proc_kb_s"] = (c.get("one_process_per_core") or {}).get("value")
+        flat["cpu_baseline.speedup_1kb_single_region"] = ns.get("speedup_single_region")
+        flat["cpu_baseline.speedup_1kb_lock_step"] = ns.get("speedup_lock_step")
+        flat["cpu_baseline.gpu_1kb_single_region_s"] = ns.get("single_region_s")
+        flat["cpu_baseline.cpu_1kb_single_region_s"] = ns.get("cpu_reference_s")
+        flat["single_region_10kb_s"] = out.get("single_region_s")
+        flat["variant_config3.items_per_s_kernel"] = (out.get("variant_config3") or {}).get("items_per_s_kernel")
+        flat["variant_config3.frac_of_hbm_peak"] = (out.get("variant_config3") or {}).get("frac_of_hbm_peak")
+        out.update(flat)
         print(json.dumps(out), flush=True)
     for _ in slots:          # the slot threads leave (and hand their runtimes back) before the process group goes
         jobs.put(None)

@@ -12,14 +12,21 @@ enum : unsigned { M_SKIP = 0, M_MATCH = 1, M_INSERT = 2, M_IGNORE = 3, M_STAY = 
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// Short serial kernels of a launch chain (walkers, table builders: < 3 % of the vector work, a fifth of a ScoreMutations chain's
-// latency under load) raise their waves' issue priority at entry: beside three sweep waves on its SIMD a lone walker wave otherwise
-// gets a quarter of the issue slots and runs 4x slower than alone, while its batch offers the chip nothing else.
+// Serial single-wave kernels of a launch chain (the backtrace walkers, the path-score pass, the per-job maxima: < 3 % of the vector
+// work, a fifth of a ScoreMutations chain's latency under load) can raise their waves' issue priority at entry: beside three sweep
+// waves on its SIMD a lone walker wave otherwise gets a quarter of the issue slots and runs 4x slower than alone, while its batch
+// offers the chip nothing else.  PS_WALKER_PRIO: the serial walkers; PS_WIDE_PRIO: the short chip-wide table builders between them.
 #ifndef PS_WALKER_PRIO
 #define PS_WALKER_PRIO 3
 #endif
+#ifndef PS_WIDE_PRIO
+#define PS_WIDE_PRIO 0
+#endif
 __device__ __forceinline__ void chain_priority() {
     if (PS_WALKER_PRIO > 0) __builtin_amdgcn_s_setprio(PS_WALKER_PRIO);
+}
+__device__ __forceinline__ void chain_priority_wide() {
+    if (PS_WIDE_PRIO > 0) __builtin_amdgcn_s_setprio(PS_WIDE_PRIO);
 }
 
 // std::lower_bound(double*, int) exactly as libstdc++ walks it (cpp/EventData.h:178)
@@ -142,7 +149,7 @@ constexpr int BTM = 8;   // the tile prefetched during a walk overlaps the curre
 struct SkewCodes {       // FLG[s][slot], s = i + j, slot = i mod P
     const unsigned short* flg; int P; int sti;
     static constexpr bool ROWFAST = false;
-    __device__ __forceinline__ void prep(int ti) { sti = __builtin_amdgcn_readfirstlane(ti > 0 ? ti % P : 0); }
+    __device__ __forceinline__ void prep(int ti, int, int) { sti = __builtin_amdgcn_readfirstlane(ti > 0 ? ti % P : 0); }
     __device__ __forceinline__ unsigned short word(int ti, int tj, int a, int c) const {
         const int r = ti - a, col = tj - c;
         int slot = sti - a;          // (ti - a) mod P, a < BT <= P
@@ -155,7 +162,7 @@ struct SkewCodes {       // FLG[s][slot], s = i + j, slot = i mod P
 template <int NT, class SRC>
 __device__ __forceinline__ void bt_load(unsigned short (*__restrict__ dst)[BT + 2], SRC& src, const int ti, const int tj, const int t) {
     constexpr int NQ = (BT * BT + NT - 1) / NT;
-    src.prep(ti);
+    src.prep(ti, tj, t);
     unsigned short tmp[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {   // all loads of a thread in flight before the first LDS store

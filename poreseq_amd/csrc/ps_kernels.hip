@@ -40,7 +40,7 @@ __device__ __forceinline__ int slot_of(int i, int P) { return i % P; }
 // one 256-thread block per job; each thread owns a contiguous chunk of levels
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_updaterefs(BatchD b) {
-    chain_priority();
+    chain_priority_wide();
     const JobD& J = b.jobs[blockIdx.x];
     JobOut* O = J.out;
     const int n = J.n0, tid = threadIdx.x;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_updaterefs(BatchD b) {
 
 // lb[j] = getrefstate(j) for j = 0 .. lbn-1 (or -1 when ref_index is empty)
 __global__ void k_lb(BatchD b, int which) {
-    chain_priority();
+    chain_priority_wide();
     const JobD& J = b.jobs[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= J.lbn) return;
@@ -110,7 +110,7 @@ __global__ void k_lb(BatchD b, int which) {
 // Entries [S, S + LO_PAD) are -1: the fill pipeline looks a few anti-diagonals past the end.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lo(BatchD b, int ndir) {
-    chain_priority();
+    chain_priority_wide();
     const int jd = blockIdx.y, job = jd / ndir, dir = jd % ndir;
     const JobD& J = b.jobs[job];
     if (J.out->inert) return;
@@ -850,7 +850,7 @@ __device__ double colmax_pair(const BatchD& b, const JobD& J, int raf, int rab, 
 
 // old score for each distinct r0 = max(start - 3, 1) ; grid (nr0, njobs), block 64
 __global__ __launch_bounds__(64) void k_old(BatchD b, const ScoreArgs* __restrict__ A) {
-    chain_priority();
+    chain_priority_wide();
     const ScoreArgs& a = A[blockIdx.z];
     if (a.oldall || (int)blockIdx.x >= a.nr0 || (int)blockIdx.y >= a.njobs) return;
     const JobD& J = b.jobs[a.job0 + blockIdx.y];
@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 
 // score[m] = -1e-6 + sum over events in order (cpp/AlignUtil.h:86, cpp/MakeMutations.cpp:51)
 __global__ void k_reduce(const ScoreArgs* __restrict__ A) {
-    chain_priority();
+    chain_priority_wide();
     const ScoreArgs& a = A[blockIdx.y];
     const int njobs = a.njobs;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1274,7 +1274,7 @@ __global__ void k_reduce(const ScoreArgs* __restrict__ A) {
 
 // latch the reference's "stripe_width == 0" decision (cpp/Alignment.cpp:51-59) for this API call
 __global__ void k_begin(BatchD b) {
-    chain_priority();
+    chain_priority_wide();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) *b.maxw = 0;
     if (j >= b.njobs) return;
@@ -1286,7 +1286,7 @@ __global__ void k_begin(BatchD b) {
 // out[job] = JobOut.best of every job of the batch (the results live in their AlignData's own slabs: gathered here so that one copy
 // returns them)
 __global__ void k_gather_best(BatchD b, double* __restrict__ out) {
-    chain_priority();
+    chain_priority_wide();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < b.njobs) out[j] = b.jobs[j].out->best;
 }

@@ -416,7 +416,10 @@ template <int K>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 8 : 4, 8))) void k_sw_trace(const SwPair* pairs, const char* chars, const int* rowsave, const int* colsave,
                                                  const int* blkmax, int* out, int* res) {
     __shared__ unsigned char codes[64][64];
-    __builtin_amdgcn_s_setprio(3);          // one serial wave per pair at the end of FindMutations' chain (ps_dev.h, chain_priority)
+#ifndef PS_WALKER_PRIO
+#define PS_WALKER_PRIO 3
+#endif
+    if (PS_WALKER_PRIO > 0) __builtin_amdgcn_s_setprio(PS_WALKER_PRIO);   // one serial wave per pair at the end of FindMutations' chain (ps_dev.h, chain_priority)
     const SwPair p = pairs[blockIdx.x];
     const int l = threadIdx.x;
     int* o = res + p.res_off;

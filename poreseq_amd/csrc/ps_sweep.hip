@@ -33,7 +33,7 @@ namespace ps {
 // column C + 1 an empty sentinel.  grid (ceil((maxC + 2) / 256), njobs)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_band(BatchD b, SweepD sw) {
-    chain_priority();
+    chain_priority_wide();
     const int jd = blockIdx.y, dir = jd % sw.ndir;
     const JobD& J = b.jobs[jd / sw.ndir];
     const SweepJob& SJ = sw.sj[jd];
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_band(BatchD b, SweepD sw) {
 // Strip q works on column t - q; it is in band iff  i0(t-q) <= qK + K  (true from some q on: i0 falls as the column does)
 // and  i1(t-q) >= qK + 1  (true up to some q).  grid (ceil((maxT + Q_PAD) / 256), njobs * ndir)
 __global__ __launch_bounds__(256) void k_qlo(BatchD b, SweepD sw) {
-    chain_priority();
+    chain_priority_wide();
     const int jd = blockIdx.y;
     const JobD& J = b.jobs[jd / sw.ndir];
     const SweepJob& SJ = sw.sj[jd];
@@ -149,22 +149,37 @@ struct StripCodes {
     const int2* band;                       // the sweep's band table of the job (forward): band[j] = rows of column j, j = 0 .. C + 1
     const int* st;                          // the sequence's 5-mers: a column without one has no cell
     int nl;                                 // lanes of a sweep (64 per wave): strip q sits on lane q mod nl
+    int ci0, ci1, cp0, cp1, cst;            // lane l: band of column tj - l, band of the column before it, its 5-mer (prep)
     static constexpr bool ROWFAST = true;   // consecutive threads take consecutive rows: K contiguous bytes per strip
-    __device__ __forceinline__ void prep(int) {}
-    // the walker's step word of cell (row, column) from the sweep's raw predicate byte (ps_sweep_body.h, CB_*): the byte says which
-    // candidates equal the cell's score and which scores are positive; whether the cell exists (its column has a 5-mer and the row is
-    // in the column's band) and whether a MATCH is a real or an implicit one (cpp/Alignment.cpp:207-220: the diagonal neighbour in
-    // the previous column's band) are looked up here — 64 consecutive threads of a tile load share the column
+    // What the sweep's predicate bits leave to the reader — does the cell exist (its column has a 5-mer, the row is in the column's
+    // band), is a MATCH real or implicit (cpp/Alignment.cpp:207-220: p0 < i <= p1 of the previous column's band) — hangs on the
+    // COLUMN: lane l of every loading wave fetches the three table entries of column tj - l once per tile, together with the tile's
+    // code words (one memory round trip, as before), and a cell picks its column's by v_readlane: the 64 threads that share a column
+    // are one wave (bt_load: row offset = thread mod 64).
+    __device__ __forceinline__ void prep(int, int tj, int t) {
+        const int col = tj - (t & 63);
+        ci0 = 1; ci1 = 0; cp0 = 0; cp1 = -1; cst = -1;
+        if (col >= 1) {
+            const int2 bc = band[col], bp = band[col - 1];
+            ci0 = bc.x; ci1 = bc.y; cp0 = bp.x; cp1 = bp.y; cst = st[col - 1];
+        }
+    }
+    // the walker's step word of cell (row, column) from the sweep's raw predicate bits (ps_sweep_body.h, CB_*)
     __device__ __forceinline__ unsigned short word(int ti, int tj, int a, int c) const {
-        const int r = ti - a, col = tj - c;
-        if (r < 1 || col < 1) return (unsigned short)0xC000u;   // outside the matrix: score 0, the walk stops
-        const int2 bc = band[col], bp = band[col - 1];
-        if (st[col - 1] < 0 || r < bc.x || r > bc.y) return (unsigned short)0xC000u;   // no cell here
-        const int q = (r - 1) / K, rr = (r - 1) - q * K;
-        const unsigned by = code_fetch(codes + (size_t)(col + q) * (nl * K), K, q & (nl - 1), rr, nl);
-        const bool vd = r > bp.x && r <= bp.y;
+        const int r = ti - a;
+        const int cu = __builtin_amdgcn_readfirstlane(c);                      // (wave-uniform: see prep)
+        const int i0 = __builtin_amdgcn_readlane(ci0, cu), i1 = __builtin_amdgcn_readlane(ci1, cu);
+        const int p0 = __builtin_amdgcn_readlane(cp0, cu), p1 = __builtin_amdgcn_readlane(cp1, cu);
+        const int sc = __builtin_amdgcn_readlane(cst, cu);
+        const int col = tj - cu;
+        const bool cell = r >= 1 && col >= 1 && sc >= 0 && r >= i0 && r <= i1;   // (outside the matrix / no cell here: score 0, the walk stops)
+        const int rs = cell ? r : 1;
+        const int q = (rs - 1) / K, rr = (rs - 1) - q * K;
+        const unsigned by = code_fetch(codes + (size_t)(max(col, 1) + q) * (nl * K), K, q & (nl - 1), rr, nl);
+        const bool vd = r > p0 && r <= p1;
         const unsigned sm = code_main_step(by, vd), ss = code_stay_step(by);
-        return (unsigned short)(sm | (ss << 8) | ((by & CB_POS) ? 0u : 0x4000u) | ((by & CB_SPOS) ? 0u : 0x8000u));
+        const unsigned w = sm | (ss << 8) | ((by & CB_POS) ? 0u : 0x4000u) | ((by & CB_SPOS) ? 0u : 0x8000u);
+        return (unsigned short)(cell ? w : 0xC000u);
     }
 };
 
@@ -202,7 +217,7 @@ __device__ __forceinline__ double cell_emission(const BatchD& b, const JobD& J, 
 
 template <bool FD>
 __global__ __launch_bounds__(256) void k_like_a(BatchD b) {
-    chain_priority();
+    chain_priority_wide();
     const JobD& J = b.jobs[blockIdx.y];
     if (J.out->inert) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(64) void k_like_b(BatchD b) {
 // ------------------------------------------------------------------------------------------------
 constexpr int LK_MAXC = 12 * 1024;      // bases per sequence the LDS index table holds (longer sequences take the host loop)
 __global__ __launch_bounds__(256) void k_likes(BatchD b, const LikeGroup* __restrict__ groups, double* __restrict__ out) {
-    chain_priority();
+    chain_priority_wide();
     __shared__ int s_idx[LK_MAXC];
     __shared__ int s_part[256];
     const LikeGroup G = groups[blockIdx.x];

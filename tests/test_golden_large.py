@@ -122,3 +122,38 @@ def test_hip_mutate_seed_list_10kb_golden(mode):
         _seed_list_case(PSAlign, swalign, "mutate_seeds_L10000")
     finally:
         api.set_sweep_min(-1)
+
+
+# ---- bench.py's own regions: digests of the reference's full schedule (tests/golden/make_golden_bench.py, oracle/_ref) ----
+def _bench_region_case(cls, sw, length):
+    """The digest bench.py's `parity_in_run` compares every timed step's region 0 with: inputs regenerated and verified by checksum,
+    the full schedule from a fresh random stream, SHA-256 of the consensus sequence + the per-call accepted-edit counts."""
+    import hashlib, json, os
+    from poreseq_amd import synth
+    from poreseq_amd.consensus import consensus_region
+    from poreseq_amd.util import DEFAULT_PARAMS
+    with open(os.path.join(G.GOLDEN, "bench_regions.json")) as fh:
+        cases = [g for g in json.load(fh)["regions"] if g["length"] == length]
+    assert cases
+    for g in cases:
+        params = dict(DEFAULT_PARAMS, verbose=0)
+        d, ev, tr = synth.make_region(g["length"], g["events"], g["seed"], sw, params)
+        assert G.input_digest(d, ev, tr) == g["input_sha256"], "synthetic generator drift"
+        pa = B.make_pa(cls, d, ev, params)
+        B.reset_rand()
+        log = []
+        seq, acc = consensus_region(pa, params, log=log)
+        assert [c for c, _, _ in log] == g["calls"] and [int(n) for _, n, _ in log] == g["nbases"], (g["seed"], log)
+        assert len(seq) == g["sequence_len"] and hashlib.sha256(seq.encode("ascii")).hexdigest() == g["sequence_sha256"], g["seed"]
+        assert acc == g["accuracy"]
+
+
+def test_oracle_bench_region_digest_1kb():
+    _bench_region_case(B.OraclePSAlign, B.oracle_swalign, 1000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("length", [1000, 10000])
+def test_hip_bench_region_digests(length):
+    """the three 10 kb regions bench.py checks in every timed step (and its 1 kb region) through the HIP library, one region at a time"""
+    _bench_region_case(PSAlign, swalign, length)

@@ -1,0 +1,40 @@
+#!/bin/bash
+# round 6: A/B of prebuilt variant libraries (tools/_libs/lib_<name>.so) on ONE box.
+#   bash tools/r06_ab.sh micro "<names>"        the sweep micro benchmark (20 / 2400 forward sweeps, 400 / 2400 both directions) per variant
+#   bash tools/r06_ab.sh bench "<names>" [reps] [bench args]   bench.py --steps 2 --warmup 1 per variant, alternating, reps times
+set -u
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it)}"
+cd "$GRAFT_REPO_ROOT"
+mode=$1; names=$2
+lib=poreseq_amd/csrc/libporeseq_hip.so
+cp $lib /tmp/lib_keep.so || exit 1
+trap 'cp /tmp/lib_keep.so "$lib"' EXIT
+mkdir -p gpurun_out
+if [ "$mode" = micro ]; then
+  export PORESEQ_SWEEP_MIN=0 PORESEQ_SPARSE_MIN=0
+  for v in $names; do
+    cp tools/_libs/lib_$v.so $lib || continue
+    for spec in "20 fwd 4,2" "240 fwd 4,2" "20 both 4,2" "120 both 4,2" "20 fwd 2,4"; do
+      set -- $spec
+      echo "$v: $(PORESEQ_SWEEP_FORM=$3 timeout 600 python3 tools/gpu_fillbatch.py $1 $2 2>&1 | tail -1)"
+    done
+  done
+else
+  reps=${3:-2}; shift; shift; shift
+  for r in $(seq 1 $reps); do
+    for v in $names; do
+      cp tools/_libs/lib_$v.so $lib || continue
+      timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu --no-extras "$@" > gpurun_out/ab_${v}_$r.json 2> gpurun_out/ab_${v}_$r.err
+      echo "$v rep $r: $(python - gpurun_out/ab_${v}_$r.json <<'PY'
+import json, sys
+try:
+    d = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")][-1]
+    r = d.get("roofline", {})
+    print("%.1f kb/s, %.0f ms/step; sweep class avg launch %.1f ms, classes ms/step %s" % (d["value"], d["ms_per_step"], r.get("avg_launch_ms", 0), {k: round(v) for k, v in r.get("all_kernel_classes_ms_per_step", {}).items()}))
+except Exception as e:
+    print("failed", e)
+PY
+)"
+    done
+  done
+fi
