@@ -499,6 +499,7 @@ int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::
     std::vector<JobOut*> info(R, nullptr);
     for (int r = 0; r < R; r++) {
         PS_TRY(as[r]->refs_to_host_async(rt));
+        as[r]->last_stream = (void*)rt->stream;
         PS_TRY(rt->down(&h_ri[r], as[r]->d_ri, (size_t)as[r]->ntot));
         PS_TRY(rt->down(&info[r], as[r]->d_out, (size_t)as[r]->E));
     }
@@ -511,6 +512,7 @@ int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::
     std::vector<VitRegionH> regs(R);
     for (int r = 0; r < R; r++) {
         regs[r].E = as[r]->E; regs[r].T = gath[r].T; regs[r].obsin = gath[r].obsin.data(); regs[r].d_model = as[r]->d_model;
+        as[r]->last_stream = (void*)rt->stream;   // (the Viterbi kernels read the model tables in the AlignData's slab)
         regs[r].rng = rngs[r]; regs[r].draw = vit_draw;
     }
     std::vector<std::vector<std::vector<int>>> paths;

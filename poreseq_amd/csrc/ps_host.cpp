@@ -427,6 +427,7 @@ int Batch::build(Runtime* rt, const std::vector<JobSpec>& specs, int ndir_, int 
     for (size_t k = 0; k < specs.size(); k++) {
         const JobSpec& s = specs[k];
         const Align* a = s.a;
+        s.a->last_stream = (void*)rt->stream;   // (every kernel over an AlignData's events goes through a Batch: ~Align, slab cache)
         const int W = a->par.realign_width;
         if (W < 0) return fail(PS_ERR_BAD_ARG, "realign_width < 0");
         // widest possible footprint 2W + 1, plus the idle slots k_fill wants between two rows of a lane; the slots actually
@@ -664,8 +665,66 @@ double Batch::fill_alg_bytes() const {
 }
 
 // ------------------------------------------------------------------------------------------ AlignData
+// The slab of an AlignData (events, derived tables, results: ~13 MB for a 10 kb region at 10x) comes from a process-wide cache and goes
+// back to it.  hipFree waits for EVERY stream of the process (43 ms per call with fourteen lock-step batches in flight: 280 regions per
+// bench step were 12 s of blocked slot threads), hipMalloc takes ~2 ms; a cached slab costs an event: recorded on the stream that
+// last had work on the slab when its AlignData goes, waited for (on the device, not the host) by the stream of the next owner.
+namespace {
+struct CachedSlab { void* p; size_t cap; hipEvent_t ev; bool pending; };
+std::mutex g_aslab_mu;
+std::vector<CachedSlab> g_aslabs;
+size_t g_aslab_bytes = 0;
+size_t aslab_cache_limit() {
+    static const size_t lim = getenv("PORESEQ_ALIGN_CACHE_GB") ? (size_t)(atof(getenv("PORESEQ_ALIGN_CACHE_GB")) * 1e9) : (size_t)8e9;
+    return lim;
+}
+}  // namespace
+
 Align::~Align() {
-    if (slab) (void)hipFree(slab);
+    if (!slab) return;
+    CachedSlab c{slab, slab_cap, nullptr, false};
+    bool keep = slab_cap > 0 && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) == hipSuccess;
+    if (keep && last_stream) {
+        if (hipEventRecord(c.ev, (hipStream_t)last_stream) == hipSuccess) c.pending = true;
+        else { (void)hipGetLastError(); (void)hipEventDestroy(c.ev); keep = false; }
+    }
+    if (keep) {
+        std::lock_guard<std::mutex> lk(g_aslab_mu);
+        if (g_aslab_bytes + c.cap <= aslab_cache_limit()) { g_aslabs.push_back(c); g_aslab_bytes += c.cap; slab = nullptr; return; }
+    }
+    if (keep) (void)hipEventDestroy(c.ev);
+    (void)hipFree(slab);
+}
+
+// a slab of at least `bytes` for an AlignData on `rt`'s stream: the smallest cached one that fits without wasting more than half of
+// itself, else a fresh allocation (with an eighth of slack, so that regions of similar size find each other's slabs)
+static int align_slab_take(Runtime* rt, size_t bytes, void** out, size_t* cap) {
+    CachedSlab got{nullptr, 0, nullptr, false};
+    {
+        std::lock_guard<std::mutex> lk(g_aslab_mu);
+        int best = -1;
+        for (int k = 0; k < (int)g_aslabs.size(); k++)
+            if (g_aslabs[k].cap >= bytes && g_aslabs[k].cap <= 2 * bytes + (1 << 20) && (best < 0 || g_aslabs[k].cap < g_aslabs[best].cap)) best = k;
+        if (best >= 0) { got = g_aslabs[best]; g_aslabs[best] = g_aslabs.back(); g_aslabs.pop_back(); g_aslab_bytes -= got.cap; }
+    }
+    if (got.p) {
+        if (got.pending) PS_HIP(hipStreamWaitEvent(rt->stream, got.ev, 0));   // (the previous owner's last work on it, if any is still queued)
+        (void)hipEventDestroy(got.ev);   // (destruction is deferred by the runtime until the wait above has been honoured)
+        *out = got.p; *cap = got.cap;
+        return PS_OK;
+    }
+    const size_t want = (bytes + bytes / 8 + ((size_t)1 << 20) - 1) >> 20 << 20;
+    if (hipMalloc(out, want) != hipSuccess) {
+        (void)hipGetLastError();
+        {   // hand the cache back and try once more
+            std::lock_guard<std::mutex> lk(g_aslab_mu);
+            for (CachedSlab& c : g_aslabs) { (void)hipEventDestroy(c.ev); (void)hipFree(c.p); }
+            g_aslabs.clear(); g_aslab_bytes = 0;
+        }
+        PS_HIP(hipMalloc(out, want));
+    }
+    *cap = want;
+    return PS_OK;
 }
 
 int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_events, const int64_t* level_off,
@@ -736,7 +795,8 @@ int Align::create(Runtime* rt, const char* seq, int64_t seq_len, int32_t n_event
     const size_t nlev = (size_t)std::max<int64_t>(ntot, 1);
     const size_t bytes = (6 + 8) * nlev * sizeof(double) + (mdl.size() + mdl8.size() + tr.size() + 2) * sizeof(double) + 256 +
                          (size_t)std::max(E, 1) * sizeof(JobOut) + 64 * 16;
-    PS_HIP(hipMalloc(&slab, bytes));
+    PS_TRY(align_slab_take(rt, bytes, &slab, &slab_cap));
+    last_stream = (void*)rt->stream;
     // the slab is filled by ONE host-to-device copy: its image is assembled in pinned staging memory first (ten copies and a memset per
     // region before: 3 000 of a bench step's copy commands)
     char* img = (char*)rt->stage.alloc(bytes);
@@ -781,6 +841,7 @@ int Align::base_batch(Runtime* rt, Batch* b, int ndir, int lb_extra) {
 int Align::refs_to_host_async(Runtime* rt) {
     pend_ra = nullptr; pend_rl = nullptr;
     if (host_refs_valid || !ntot) { host_refs_valid = true; return PS_OK; }
+    last_stream = (void*)rt->stream;
     PS_TRY(rt->down(&pend_ra, d_ra, (size_t)ntot));
     PS_TRY(rt->down(&pend_rl, d_rl, (size_t)ntot));
     return PS_OK;

@@ -72,6 +72,8 @@ struct Align {
     std::vector<double> h_mean, h_stdv, h_ra, h_rl, h_model, h_trans;   // h_trans: log transition probabilities [E][4]
     bool host_refs_valid = true;
     void* slab = nullptr;
+    size_t slab_cap = 0;
+    void* last_stream = nullptr;   // the stream that last had work on the slab enqueued (hipStream_t; Batch::build, create, refs_to_host): ~Align
     double *d_mean = nullptr, *d_stdv = nullptr, *d_lsd = nullptr, *d_ra = nullptr, *d_rl = nullptr, *d_ri = nullptr;
     double *d_model = nullptr, *d_trans = nullptr;
     double *d_model8 = nullptr, *d_lev[2] = {nullptr, nullptr};   // k_fill's tables (ps_internal.h, JobD)
