@@ -85,9 +85,10 @@ __global__ __launch_bounds__(256) void k_qlo(BatchD b, SweepD sw) {
 template <int K, bool FD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PS_SWEEP_WPE(K), PS_SWEEP_WPE(K))))
 void k_sweep(BatchD b, SweepD sw) {
+    __shared__ __attribute__((aligned(16))) char mring[mring_bytes(1)];
     const JobD& J = b.jobs[blockIdx.x];
     if (J.out->inert) return;
-    sweep_body<K, 1, 0, 0, FD>(b, sw, J, sw.sj[blockIdx.x], nullptr, nullptr);
+    sweep_body<K, 1, 0, 0, FD>(b, sw, J, sw.sj[blockIdx.x], nullptr, nullptr, mring);
 }
 
 // Alignment::update batches: one wave per (job, direction), sweep job jd = 2 * job + direction
@@ -95,11 +96,12 @@ template <int K, bool FD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PS_SWEEP_WPE(K), PS_SWEEP_WPE(K))))
 void k_sweep2(BatchD b, SweepD sw) {
     __shared__ unsigned long long ring[ring_cols(1)];
+    __shared__ __attribute__((aligned(16))) char mring[mring_bytes(1)];
     const int jd = blockIdx.x;
     const JobD& J = b.jobs[jd >> 1];
     if (J.out->inert) return;
-    if ((jd & 1) == 0) sweep_body<K, 1, 0, 1, FD>(b, sw, J, sw.sj[jd], ring, nullptr);
-    else sweep_body<K, 1, 1, 1, FD>(b, sw, J, sw.sj[jd], ring, nullptr);
+    if ((jd & 1) == 0) sweep_body<K, 1, 0, 1, FD>(b, sw, J, sw.sj[jd], ring, nullptr, mring);
+    else sweep_body<K, 1, 1, 1, FD>(b, sw, J, sw.sj[jd], ring, nullptr, mring);
 }
 
 // Alignment::update batches whose edit list reads few columns: the same sweeps with column-sparse records
@@ -107,11 +109,12 @@ template <int K, bool FD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PS_SWEEP_WPE(K), PS_SWEEP_WPE(K))))
 void k_sweeps(BatchD b, SweepD sw) {
     __shared__ unsigned long long ring[ring_cols(1)];
+    __shared__ __attribute__((aligned(16))) char mring[mring_bytes(1)];
     const int jd = blockIdx.x;
     const JobD& J = b.jobs[jd >> 1];
     if (J.out->inert) return;
-    if ((jd & 1) == 0) sweep_body<K, 1, 0, 2, FD>(b, sw, J, sw.sj[jd], ring, nullptr);
-    else sweep_body<K, 1, 1, 2, FD>(b, sw, J, sw.sj[jd], ring, nullptr);
+    if ((jd & 1) == 0) sweep_body<K, 1, 0, 2, FD>(b, sw, J, sw.sj[jd], ring, nullptr, mring);
+    else sweep_body<K, 1, 1, 2, FD>(b, sw, J, sw.sj[jd], ring, nullptr, mring);
 }
 
 // the global maximum and its first cell — smallest column, then smallest row (cpp/Alignment.cpp:158, 270: strict '>' over columns
@@ -173,7 +176,9 @@ struct StripCodes {
         const int sc = __builtin_amdgcn_readlane(cst, cu);
         const int col = tj - cu;
         const bool cell = r >= 1 && col >= 1 && sc >= 0 && r >= i0 && r <= i1;   // (outside the matrix / no cell here: score 0, the walk stops)
-        const int rs = cell ? r : 1;
+        // (the code's address must not wait for the column tables — they are in flight with the tile's code words, one memory round
+        //  trip for both: any row >= 1 of any column >= 1 has a code word, in band or not)
+        const int rs = max(r, 1);
         const int q = (rs - 1) / K, rr = (rs - 1) - q * K;
         const unsigned by = code_fetch(codes + (size_t)(max(col, 1) + q) * (nl * K), K, q & (nl - 1), rr, nl);
         const bool vd = r > p0 && r <= p1;

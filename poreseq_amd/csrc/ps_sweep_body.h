@@ -82,6 +82,20 @@ __device__ __forceinline__ double wave_ror1(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// ---- model rows through LDS (the north_star's staging, in the form that fits beside six sweeps per CU) ----
+// A lane's column changes every step, so its 64-byte model row does too: straight from global memory that is four 16-byte gathers per
+// lane and step with 64 different cache lines per instruction — 5 G L1 -> L2 requests and 43 GB of HBM / MALL fetch per 2 400-sweep launch
+// (profiles/r05_c_sweep_pmc.md), a quarter of a CU's L1 tag bandwidth at six sweeps per CU.  But the columns in use on one step are a
+// WINDOW (strip q works on column t - q: at most NL - 1 consecutive columns) that slides by at most one column per step: each column's
+// row is fetched ONCE per sweep into a ring in LDS indexed by column (slot = column mod 2 NL, 80-byte pitch: eight consecutive slots
+// cover all 32 banks, a 16-byte read per lane is conflict-free) by wave 0, sixteen columns per batch (64 lanes x 16 bytes), NL columns
+// ahead of the newest column in use; the lanes read their rows from LDS.  640 KB of model rows per 10 kb sweep leave L2 instead of 100 MB.
+#ifndef PS_MODEL_RING
+#define PS_MODEL_RING 1
+#endif
+__host__ __device__ constexpr int mring_slots(int nw) { return 128 * nw; }          // 2 NL columns
+__host__ __device__ constexpr int mring_bytes(int nw) { return PS_MODEL_RING ? (mring_slots(nw) + 1) * MODEL_ROW_BYTES : 16; }   // (+ a spare slot: f_write)
+
 // columns of the LDS ring of per-column maxima: the widest window (NL - 1 strips) + the 64 steps between two flushes, rounded up
 __host__ __device__ constexpr int ring_cols(int nw) { return nw <= 2 ? 256 : 512; }
 constexpr int HAND_DOUBLES = 4;   // LDS hand-off record of a wave's last lane: {main, stay (+ emission), main + emission, -}
@@ -102,9 +116,10 @@ constexpr int HAND_DOUBLES = 4;   // LDS hand-off record of a wave's last lane: 
 // covered by the step's emissions, which do not depend on it.  Nothing else crosses waves: the ring of column maxima is shared
 // (LDS atomics), every other table is per lane.
 template <int K, int NW, int DIR, int MODE, bool FD>
-__device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, const JobD& J, const SweepJob& SJ, unsigned long long* ring, double* hand) {
+__device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, const JobD& J, const SweepJob& SJ, unsigned long long* ring, double* hand, char* mring) {
     constexpr int NL = 64 * NW;
     constexpr int RING = ring_cols(NW);
+    constexpr int RM = mring_slots(NW);                            // slots of the model-row ring
     const int lane = threadIdx.x;                                  // lane of the sweep, 0 .. NL - 1
     const int wv = NW > 1 ? uni((int)threadIdx.x >> 6) : 0;       // its wave
     const int C = uni(J.C), T = uni(SJ.T), n0 = uni(J.n0);
@@ -127,7 +142,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     const double NINF = -__builtin_inf();
 
     // ---- what a lane fetches ahead of the step it is needed on
-    struct Ahead { int p1, i0, i1, sc, kc; };   // last band row of column j - 1, band rows and 5-mer of the lane's column j; kc: kept-column index (MODE 2)
+    struct Ahead { int p1, i0, i1, sc, kc, ro; };   // last band row of column j - 1, band rows and 5-mer of the lane's column j; kc: kept-column index (MODE 2); ro: byte offset of the column's model row in the LDS ring
     gcip keep = (gcip)uni_ptr(J.keep[DIR]);
     const int pitch = uni(J.pitch);
     // (every per-lane address below is a wave-uniform base in scalar registers + an unsigned 32-bit byte offset: the `saddr` form of
@@ -149,12 +164,75 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         // (forward column j holds states[j - 1], backward column j states[C - j]; ints of -1 around the list)
         a.sc = *(const PS_GLOBAL int*)(st_c + (unsigned)(4 * (DIR == 0 ? j : C - j)));
         a.kc = MODE == 2 ? *(const PS_GLOBAL int*)(keep_c + (unsigned)(4 * j)) : -1;
+        a.ro = PS_MODEL_RING ? (j & (RM - 1)) * MODEL_ROW_BYTES : 0;
         return a;
     };
-    auto model_row = [&](int state, double (&m)[8]) {
-        const PS_GLOBAL v2d* row = (const PS_GLOBAL v2d*)(model + (unsigned)max(state, 0) * (unsigned)MODEL_ROW_BYTES);
-        const v2d q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+    auto model_row = [&](const Ahead& a, double (&m)[8]) {
+        v2d q0, q1, q2, q3;
+        if (PS_MODEL_RING) {
+            const v2d* row = (const v2d*)(mring + a.ro);
+            q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3];
+        } else {
+            const PS_GLOBAL v2d* row = (const PS_GLOBAL v2d*)(model + (unsigned)max(a.sc, 0) * (unsigned)MODEL_ROW_BYTES);
+            q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3];
+        }
         m[0] = q0.x; m[1] = q0.y; m[2] = q1.x; m[3] = q1.y; m[4] = q2.x; m[5] = q2.y; m[6] = q3.x; m[7] = q3.y;
+    };
+
+    // ---- the feeder of the model-row ring (wave 0; every decision below is wave-uniform).  Columns 1 .. jf are in the ring.
+    // Steady state, per step: the first eight lanes load the row quarters of the next TWO columns at the top of the step (their 5-mer
+    // states arrived as scalar loads issued the step before) and write them to LDS at the end of the same step, behind the cells —
+    // nothing in flight is carried from step to step in vector registers (values that are would meet in register copies, i.e. in
+    // full waits).  Two columns a step against at most one consumed: the ring runs ahead until the next column would overwrite its
+    // slot's previous tenant (column - RM) before that one is older than the oldest column any strip can still be on — the newest
+    // column in use, jn = t - qlo(t), minus the widest window, NL - 2 (both only grow while strips are in band: qlo never falls, and
+    // a strip that has left the band does not come back) — i.e. NL columns ahead of jn.  At the start of a sweep and on the step
+    // after a stretch without any strip in band, the columns the next step reads may not be there yet: all 64 lanes then load
+    // sixteen columns at a time on the spot (two dependent round trips each: rare).
+    const bool feeder = PS_MODEL_RING && wv == 0;
+    typedef const __attribute__((address_space(4))) int* kst_t;
+    kst_t st_k = (kst_t)uni_ptr(J.st);
+    int jf = 0;                         // columns 1 .. jf are in the ring (visible behind the next barrier)
+    int fs0 = -1, fs1 = -1, fsb = -1;   // 5-mer states of columns fsb + 1, fsb + 2 (scalar registers; fsb < 0: none loaded)
+    auto st_of = [&](int c) -> int { return st_k[DIR == 0 ? c - 1 : C - c]; };   // (ints of -1 around the list)
+    auto ring_at = [&](int c, int q16) -> v4i* { return (v4i*)(mring + (c <= C ? (c & (RM - 1)) : RM) * MODEL_ROW_BYTES + q16); };   // (behind the last column: a spare slot)
+    auto feed_now = [&](int hi) {       // columns up to hi, at once
+        const int fcol = (lane & 63) >> 2, fq16 = (lane & 3) * 16;
+        const int lo = max(1, hi - (NL - 2));
+        if (jf < lo - 1) jf = lo - 1;   // (nobody is on the columns in between any more)
+        while (jf < hi) {
+            const int c = jf + 1 + fcol, cc = min(c, max(C, 1));
+            const int state = *(const PS_GLOBAL int*)(st_c + (unsigned)(4 * (DIR == 0 ? cc : C - cc)));
+            const v4i row = *(const PS_GLOBAL v4i*)(model + (unsigned)max(state, 0) * (unsigned)MODEL_ROW_BYTES + (unsigned)fq16);
+            *ring_at(c, fq16) = row;
+            jf += 16;
+        }
+        fsb = -1;
+    };
+    v4i frow = {0, 0, 0, 0};
+    bool fput = false;                  // (uniform) frow holds the row quarters of columns jf + 1, jf + 2: f_end writes them
+    // top of step t.  hi_next: the newest column a lane reads a row of behind this step's barrier (0: none); jn_now: the newest
+    // column in use on this step (0: none)
+    auto f_top = [&](int hi_next, int jn_now) {
+        if (!feeder) return;
+        if (hi_next > 0 && jf < min(C, hi_next)) feed_now(min(C, hi_next));
+        fput = false;
+        if (jf < C && fsb == jf && jn_now > 0 && jf + 2 <= jn_now + NL + 1) {
+            if ((lane & 63) < 8) {
+                const int state = (lane & 4) ? fs1 : fs0;
+                frow = *(const PS_GLOBAL v4i*)(model + (unsigned)max(state, 0) * (unsigned)MODEL_ROW_BYTES + (unsigned)((lane & 3) * 16));
+            }
+            fput = true;
+        }
+    };
+    // end of step t (behind the cells: the loads of f_top have had the step to arrive)
+    auto f_end = [&]() {
+        if (!feeder) return;
+        if (fput) {
+            if ((lane & 63) < 8) *ring_at(jf + 1 + ((lane & 4) >> 2), (lane & 3) * 16) = frow;
+            jf += 2;
+        }
+        if (jf < C && fsb != jf) { fsb = jf; fs0 = st_of(min(jf + 1, C)); fs1 = st_of(min(jf + 2, C)); }
     };
 
     // ---- lane state
@@ -185,7 +263,12 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     int ql0 = QLO[1], ql1 = QLO[2], ql2 = QLO[3];   // qlo of step t, t + 1, t + 2 (scalar registers; T + Q_PAD entries, -1 behind T)
     Ahead aA = fetch(1, ql0), aB = fetch(2, ql1), aC = aB;   // three pipeline stages whose roles rotate with the step (the loop is unrolled by three)
     double mr[8];
-    model_row(aA.sc, mr);
+    if (PS_MODEL_RING) {
+        // the rows of step 1's columns (every lane's column is clamped into 1 .. C: column 1 where its strip has not started)
+        if (feeder) { feed_now(min(max(C, 1), ql0 >= 0 ? max(1 - ql0, 1) : 1)); if (jf < C) { fsb = jf; fs0 = st_of(min(jf + 1, C)); fs1 = st_of(min(jf + 2, C)); } }
+        if (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    model_row(aA, mr);
     // The level records of the strip a lane works on at step t + 1 are fetched during step t, behind the step's emissions (the last
     // readers of the old ones): a strip's rows are read once per sweep, so the loads miss every cache, and issued at the top of
     // the step they are first used on they stalled the wave — and behind the step's barrier the whole workgroup — for the whole miss.
@@ -272,7 +355,11 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
 #pragma unroll
             for (int r = 0; r < K; r++) { pm[r] = NINF; if (DIR) pe[r] = NINF; }
         }
-        const int ql3 = QLO[t + 3];                                  // (one step further ahead than it is needed: the scalar load's latency stays off the step)
+        if (PS_MODEL_RING) f_top(ql1 >= 0 ? t + 1 - ql1 : 0, ql >= 0 ? t - ql : 0);   // (before the step's barrier: what it writes now is read behind it)
+        // (qlo one step further ahead than it is needed: the scalar load's latency stays off the step.  With the model rows in LDS the
+        //  emissions below wait for LDS reads — the same counter as scalar loads — so the load is issued behind them, further down)
+        int ql3 = 0;
+        if (!PS_MODEL_RING) ql3 = QLO[t + 3];
         a2 = fetch(t + 2, ql2);
         __builtin_amdgcn_sched_barrier(0);                           // (the step's loads are issued before its first emission waits for the model row)
         // emissions of the lane's K cells first: the model row is then free to receive the next column's (one step of lead).  NW > 1:
@@ -299,7 +386,8 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
         }
         put_pending(t - 1);
         load_levels(ql1);
-        model_row(a1.sc, mr);
+        model_row(a1, mr);
+        if (PS_MODEL_RING) ql3 = QLO[t + 3];
         pend = live;
         // (a step without a strip in band — the steps a last round of three adds behind T - 1 — runs the cells too, on no band: a uniform
         //  branch around them makes every loop-carried value a phi of two definitions, eight register copies per step)
@@ -444,6 +532,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
             *(v2d*)h = (v2d){bot_m, bot_s};
             if (DIR) h[2] = bot_e;
         }
+        if (PS_MODEL_RING) f_end();
         ql0 = ql1; ql1 = ql2; ql2 = ql3;
     };
 

@@ -26,9 +26,10 @@ template <int K, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PS_SWEEPW_WPE(K), PS_SWEEPW_WPE(K))))
 void k_sweep_w(BatchD b, SweepD sw) {
     __shared__ double hand[2 * NW * HAND_DOUBLES];
+    __shared__ __attribute__((aligned(16))) char mring[mring_bytes(NW)];
     const JobD& J = b.jobs[blockIdx.x];
     if (J.out->inert) return;
-    sweep_body<K, NW, 0, 0, true>(b, sw, J, sw.sj[blockIdx.x], nullptr, hand);
+    sweep_body<K, NW, 0, 0, true>(b, sw, J, sw.sj[blockIdx.x], nullptr, hand, mring);
 }
 
 template <int K, int NW>
@@ -36,11 +37,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PS_SWEE
 void k_sweep2_w(BatchD b, SweepD sw) {
     __shared__ unsigned long long ring[ring_cols(NW)];
     __shared__ double hand[2 * NW * HAND_DOUBLES];
+    __shared__ __attribute__((aligned(16))) char mring[mring_bytes(NW)];
     const int jd = blockIdx.x;
     const JobD& J = b.jobs[jd >> 1];
     if (J.out->inert) return;
-    if ((jd & 1) == 0) sweep_body<K, NW, 0, 1, true>(b, sw, J, sw.sj[jd], ring, hand);
-    else sweep_body<K, NW, 1, 1, true>(b, sw, J, sw.sj[jd], ring, hand);
+    if ((jd & 1) == 0) sweep_body<K, NW, 0, 1, true>(b, sw, J, sw.sj[jd], ring, hand, mring);
+    else sweep_body<K, NW, 1, 1, true>(b, sw, J, sw.sj[jd], ring, hand, mring);
 }
 
 template <int K, int NW>
@@ -48,11 +50,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PS_SWEE
 void k_sweeps_w(BatchD b, SweepD sw) {
     __shared__ unsigned long long ring[ring_cols(NW)];
     __shared__ double hand[2 * NW * HAND_DOUBLES];
+    __shared__ __attribute__((aligned(16))) char mring[mring_bytes(NW)];
     const int jd = blockIdx.x;
     const JobD& J = b.jobs[jd >> 1];
     if (J.out->inert) return;
-    if ((jd & 1) == 0) sweep_body<K, NW, 0, 2, true>(b, sw, J, sw.sj[jd], ring, hand);
-    else sweep_body<K, NW, 1, 2, true>(b, sw, J, sw.sj[jd], ring, hand);
+    if ((jd & 1) == 0) sweep_body<K, NW, 0, 2, true>(b, sw, J, sw.sj[jd], ring, hand, mring);
+    else sweep_body<K, NW, 1, 2, true>(b, sw, J, sw.sj[jd], ring, hand, mring);
 }
 
 template <int K, int NW>

@@ -2,6 +2,7 @@
 # round 6: A/B of prebuilt variant libraries (tools/_libs/lib_<name>.so) on ONE box.
 #   bash tools/r06_ab.sh micro "<names>"        the sweep micro benchmark (20 / 2400 forward sweeps, 400 / 2400 both directions) per variant
 #   bash tools/r06_ab.sh bench "<names>" [reps] [bench args]   bench.py --steps 2 --warmup 1 per variant, alternating, reps times
+#   a name of the form  lib@VAR=value,VAR2=value  runs library variant `lib` (`.` = the tree's own) under those environment variables
 set -u
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it)}"
 cd "$GRAFT_REPO_ROOT"
@@ -22,9 +23,11 @@ if [ "$mode" = micro ]; then
 else
   reps=${3:-2}; shift; shift; shift
   for r in $(seq 1 $reps); do
-    for v in $names; do
-      cp tools/_libs/lib_$v.so $lib || continue
-      timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu --no-extras "$@" > gpurun_out/ab_${v}_$r.json 2> gpurun_out/ab_${v}_$r.err
+    for spec in $names; do
+      l=${spec%%@*}; envs=""; [ "$spec" != "$l" ] && envs=$(echo "${spec#*@}" | tr ',' ' ')
+      v=$(echo "$spec" | tr '@=,/' '____')
+      if [ "$l" = "." ]; then cp /tmp/lib_keep.so $lib; else cp tools/_libs/lib_$l.so $lib || continue; fi
+      env $envs timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu --no-extras "$@" > gpurun_out/ab_${v}_$r.json 2> gpurun_out/ab_${v}_$r.err
       echo "$v rep $r: $(python - gpurun_out/ab_${v}_$r.json <<'PY'
 import json, sys
 try:
