@@ -150,30 +150,37 @@ struct SkewCodes {       // FLG[s][slot], s = i + j, slot = i mod P
     const unsigned short* flg; int P; int sti;
     static constexpr bool ROWFAST = false;
     __device__ __forceinline__ void prep(int ti, int, int) { sti = __builtin_amdgcn_readfirstlane(ti > 0 ? ti % P : 0); }
-    __device__ __forceinline__ unsigned short word(int ti, int tj, int a, int c) const {
+    // fetch: the load of one cell's word; decode: what the walker reads (here: the word itself)
+    __device__ __forceinline__ unsigned fetch(int ti, int tj, int a, int c) const {
         const int r = ti - a, col = tj - c;
         int slot = sti - a;          // (ti - a) mod P, a < BT <= P
         if (slot < 0) slot += P;
-        return (r >= 1 && col >= 1) ? flg[(int64_t)(r + col) * P + slot] : (unsigned short)0xC000u;   // outside the matrix: score 0, the walk stops
+        return (r >= 1 && col >= 1) ? flg[(int64_t)(r + col) * P + slot] : 0xC000u;   // outside the matrix: score 0, the walk stops
     }
+    __device__ __forceinline__ unsigned short decode(unsigned raw, int, int, int, int) const { return (unsigned short)raw; }
 };
 
-// cooperative load of the BT x BT step-word tile whose corner (largest row / column) is (ti, tj); NT threads, t in [0, NT)
+// cooperative load of the BT x BT step-word tile whose corner (largest row / column) is (ti, tj); NT threads, t in [0, NT).
+// Two passes: every load of a thread is in flight (with the per-column tables a source fetches in prep) before the first word is
+// decoded and stored — one memory round trip per tile.
 template <int NT, class SRC>
 __device__ __forceinline__ void bt_load(unsigned short (*__restrict__ dst)[BT + 2], SRC& src, const int ti, const int tj, const int t) {
     constexpr int NQ = (BT * BT + NT - 1) / NT;
     src.prep(ti, tj, t);
-    unsigned short tmp[NQ];
+    unsigned raw[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {   // all loads of a thread in flight before the first LDS store
+    for (int q = 0; q < NQ; q++) {
         const int idx = min(t + NT * q, BT * BT - 1);
         const int a = SRC::ROWFAST ? idx % BT : idx / BT, c = SRC::ROWFAST ? idx / BT : idx % BT;
-        tmp[q] = src.word(ti, tj, a, c);
+        raw[q] = src.fetch(ti, tj, a, c);
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         const int idx = t + NT * q;
-        if (idx < BT * BT) { const int a = SRC::ROWFAST ? idx % BT : idx / BT, c = SRC::ROWFAST ? idx / BT : idx % BT; dst[a][c] = tmp[q]; }
+        const int ic = min(idx, BT * BT - 1);
+        const int a = SRC::ROWFAST ? ic % BT : ic / BT, c = SRC::ROWFAST ? ic / BT : ic % BT;
+        const unsigned short w = src.decode(raw[q], ti, tj, a, c);
+        if (idx < BT * BT) dst[a][c] = w;
     }
 }
 

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1370,6 +1371,10 @@ static int score_mutations_planned(Runtime* rt, const std::vector<Align*>& as, c
                                    const std::vector<std::vector<Mut>*>& outs, const std::vector<double*>* delta_out, std::vector<EditPlan>& plan) {
     Tick tk("score_mutations");
     const int R = (int)as.size();
+    {   // experiment: how much of a bench step is the latency of a chain?  PORESEQ_DEBUG_SLEEP_US of host sleep per ScoreMutations call
+        static const int us = getenv("PORESEQ_DEBUG_SLEEP_US") ? atoi(getenv("PORESEQ_DEBUG_SLEEP_US")) : 0;
+        if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us));
+    }
     // Which columns of the score matrices will the edit lists read?  A short list (FindMutations' found edits, the rounds of
     // MakeMutations' recursion: tens to hundreds of edits per region) reads a few percent of them: the fills then run as strip
     // sweeps that keep those columns only (ps_sweep.hip, k_sweeps) — a few MB per alignment instead of 2 x 110 MB.  A list that

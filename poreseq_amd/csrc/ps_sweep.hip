@@ -12,15 +12,17 @@
 // (ps_sweepw.hip: lane q mod 128 / 256 of a workgroup of two / four waves, the cross-wave neighbour through LDS)
 // owns strip q and walks it one column per step, K cells top to bottom; strip q works on column j at step t = j + q, so the
 // lane one up finished the same column one step earlier: the cell above a strip's first row arrives by one wave-rotate DPP move
-// of {main, stay}, the rest of a column's vertical dependencies are the lane's own registers.  No LDS, no barrier, no other
-// wave: 2048 sweeps are resident on the chip at two waves per SIMD.  The strips in band on one step form a contiguous window
-// [qlo(t), qhi(t)] (both band ends are monotone in the column); K is chosen so that the widest window leaves two lanes idle,
+// of {main, stay}, the rest of a column's vertical dependencies are the lane's own registers.  One wavefront per sweep needs no
+// barrier and no other wave.  The strips in band on one step form a contiguous window
+// [qlo(t), qhi(t)] (both band ends are monotone in the column); K is chosen so that the widest window leaves one lane idle,
 // and a lane's strip is qlo + ((lane - qlo) mod 64).
-//   per step and lane (not per cell): band of its column and the previous one (16-byte load, two steps ahead), the column's
-//   5-mer (two steps ahead) and its 64-byte model row (one step ahead, straight from global memory / L2: one row serves K cells);
+//   per step and lane (not per cell): band of its column and the last band row of the previous one (12-byte load, two steps ahead),
+//   the column's 5-mer (two steps ahead) and its 64-byte model row, one step ahead, from a ring in LDS indexed by column that wave 0
+//   fills — each column's row leaves L2 once per sweep (ps_sweep_body.h: "model rows through LDS"; round 6; the north_star's staging);
 //   per strip: the K level records, kept in registers for the ~2W/slope columns the strip stays in band.
-// What leaves the chip: ONE BYTE per cell — main step (3 bits, 7 = implicit), stay step (2 bits), the two "score <= 0" bits
-// (32 / 64) the walker stops on — laid out [step][row group][lane] so every store is a full coalesced line; plus one {best, i, j} record
+// What leaves the chip: SEVEN BITS per cell — the raw predicates of the fill (which candidate equals the maximum, EXTEND > STAY,
+// the two "score > 0" tests the walker stops on; ps_sweep_body.h, CB_*), shifted into a register by add-with-carry and decoded by the
+// reader (StripCodes below) — laid out [step][row group][lane] so every store is a full coalesced line; plus one {best, i, j} record
 // per strip.  No score matrix: the scores along the backtrace path (ref_like) are recomputed afterwards.  A cell on the path
 // equals its predecessor's score plus the move's terms (cpp/Alignment.cpp:196-237), with the very operations the fill used, so a
 // serial pass along the path (k_like_b: one wave per job, ~3 dependent additions per level) reproduces them bit for bit.
@@ -167,20 +169,20 @@ struct StripCodes {
             ci0 = bc.x; ci1 = bc.y; cp0 = bp.x; cp1 = bp.y; cst = st[col - 1];
         }
     }
-    // the walker's step word of cell (row, column) from the sweep's raw predicate bits (ps_sweep_body.h, CB_*)
-    __device__ __forceinline__ unsigned short word(int ti, int tj, int a, int c) const {
+    // fetch: the cell's 32 / 16 / 8-bit code word (its address must not wait for the column tables: any row >= 1 of any column >= 1
+    // has one, in band or not); decode: the walker's step word from the sweep's raw predicate bits (ps_sweep_body.h, CB_*)
+    __device__ __forceinline__ unsigned fetch(int ti, int tj, int a, int c) const {
+        const int rs = max(ti - a, 1), col = max(tj - c, 1);
+        const int q = (rs - 1) / K, rr = (rs - 1) - q * K;
+        return code_fetch(codes + (size_t)(col + q) * (nl * K), K, q & (nl - 1), rr, nl);
+    }
+    __device__ __forceinline__ unsigned short decode(unsigned by, int ti, int tj, int a, int c) const {
         const int r = ti - a;
         const int cu = __builtin_amdgcn_readfirstlane(c);                      // (wave-uniform: see prep)
         const int i0 = __builtin_amdgcn_readlane(ci0, cu), i1 = __builtin_amdgcn_readlane(ci1, cu);
         const int p0 = __builtin_amdgcn_readlane(cp0, cu), p1 = __builtin_amdgcn_readlane(cp1, cu);
         const int sc = __builtin_amdgcn_readlane(cst, cu);
-        const int col = tj - cu;
-        const bool cell = r >= 1 && col >= 1 && sc >= 0 && r >= i0 && r <= i1;   // (outside the matrix / no cell here: score 0, the walk stops)
-        // (the code's address must not wait for the column tables — they are in flight with the tile's code words, one memory round
-        //  trip for both: any row >= 1 of any column >= 1 has a code word, in band or not)
-        const int rs = max(r, 1);
-        const int q = (rs - 1) / K, rr = (rs - 1) - q * K;
-        const unsigned by = code_fetch(codes + (size_t)(max(col, 1) + q) * (nl * K), K, q & (nl - 1), rr, nl);
+        const bool cell = r >= 1 && tj - cu >= 1 && sc >= 0 && r >= i0 && r <= i1;   // (outside the matrix / no cell here: score 0, the walk stops)
         const bool vd = r > p0 && r <= p1;
         const unsigned sm = code_main_step(by, vd), ss = code_stay_step(by);
         const unsigned w = sm | (ss << 8) | ((by & CB_POS) ? 0u : 0x4000u) | ((by & CB_SPOS) ? 0u : 0x8000u);

@@ -128,11 +128,7 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
     kcip QHI = (kcip)uni_ptr(sw.qhi + SJ.q_off);
     gcip band = (gcip)uni_ptr((const int*)(sw.band + SJ.band_off));
     gcip st = (gcip)uni_ptr(J.st);
-#ifdef PS_DEBUG_ONE_MODEL   // pricing experiment (wrong results): every sweep of a launch reads the FIRST job's model table — what the model rows' L2 / HBM traffic costs
-    const PS_GLOBAL char* model = (const PS_GLOBAL char*)uni_ptr((const char*)b.jobs[0].model8);
-#else
     const PS_GLOBAL char* model = (const PS_GLOBAL char*)uni_ptr((const char*)J.model8);
-#endif
     const PS_GLOBAL v4d* levs = (const PS_GLOBAL v4d*)uni_ptr(J.lev[DIR]);
     PS_GLOBAL unsigned char* codes = (PS_GLOBAL unsigned char*)uni_ptr(sw.codes + SJ.codes_off);
     PS_GLOBAL char* rec = (PS_GLOBAL char*)uni_ptr((char*)(b.rec + J.mat_off[DIR]));

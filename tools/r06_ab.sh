@@ -11,7 +11,21 @@ lib=poreseq_amd/csrc/libporeseq_hip.so
 cp $lib /tmp/lib_keep.so || exit 1
 trap 'cp /tmp/lib_keep.so "$lib"' EXIT
 mkdir -p gpurun_out
-if [ "$mode" = micro ]; then
+if [ "$mode" = kstats ]; then
+  # per-kernel average durations (rocprofv3 --kernel-trace --stats) of the forward micro benchmark, 20 regions x 10 events, per variant
+  export PORESEQ_SWEEP_MIN=0 PORESEQ_SPARSE_MIN=0 PORESEQ_SWEEP_FORM=4,2
+  for v in $names; do
+    cp tools/_libs/lib_$v.so $lib || continue
+    rm -rf /tmp/ks_$v; (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$v -o r -- python3 $GRAFT_REPO_ROOT/tools/gpu_fillbatch.py ${3:-20} ${4:-fwd} > /tmp/ks_$v.log 2>&1)
+    echo "== $v: $(tail -1 /tmp/ks_$v.log)"
+    python3 - "$(find /tmp/ks_$v -name '*kernel_stats.csv' | head -1)" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:9]:
+    print("   %-40s calls %5s  avg %9.1f us" % (r["Name"].split("(")[0].replace("void ", "").replace("ps::", "")[:40], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+  done
+elif [ "$mode" = micro ]; then
   export PORESEQ_SWEEP_MIN=0 PORESEQ_SPARSE_MIN=0
   for v in $names; do
     cp tools/_libs/lib_$v.so $lib || continue
