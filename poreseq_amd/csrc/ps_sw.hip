@@ -180,6 +180,9 @@ __global__ __launch_bounds__(64 * WW) void k_sw_fill(const SwPair* pairs, const 
             const int i0 = c * SWB;
             int bnd = bd1;
             if (w > 0 && l < SWB && i0 + l < p.n1) bnd = hand[w - 1][(s - 1) & 1][l];
+            int hl[SWB];
+#pragma unroll
+            for (int r = 0; r < SWB; r++) hl[r] = 0;
 #pragma unroll
             for (int r = 0; r < SWB; r++) {
                 if (i0 + r < p.n1) {
@@ -190,7 +193,19 @@ __global__ __launch_bounds__(64 * WW) void k_sw_fill(const SwPair* pairs, const 
                     for (int k = 0; k < K; k++) bmk[k] = max(bmk[k], G[k]);
                     const int hlast = G[K - 1] - 8 * (K - 1);
                     if (l == 63) hand[w][s & 1][r] = hlast;
-                    if (keeps) csave[i0 + r + 1] = hlast;
+                    hl[r] = hlast;
+                }
+            }
+            // the kept boundary column's rows of this chunk in two 16-byte stores (round 6: one 4-byte store per row and kept column was
+            // 101 G of a bench step's 225 G L1 -> L2 write requests, profiles/r06_mem.json)
+            if (keeps) {
+                if (i0 + SWB <= p.n1) {
+                    typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    *(v4i_a4*)(csave + i0 + 1) = (v4i_a4){hl[0], hl[1], hl[2], hl[3]};
+                    *(v4i_a4*)(csave + i0 + 5) = (v4i_a4){hl[4], hl[5], hl[6], hl[7]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < SWB; r++) if (i0 + r < p.n1) csave[i0 + r + 1] = hl[r];
                 }
             }
             const int iend = min(i0 + SWB, p.n1);
@@ -334,6 +349,9 @@ __global__ __launch_bounds__(64 * WW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const int i0 = c * SWB;
             int bnd = bd1;
             if (w > 0 && l < SWB && i0 + l < p.n1) bnd = hand[w - 1][(s - 1) & 1][l];
+            int hl[SWB];
+#pragma unroll
+            for (int r = 0; r < SWB; r++) hl[r] = 0;
 #pragma unroll
             for (int r = 0; r < SWB; r++) {
                 if (i0 + r < p.n1) {
@@ -354,7 +372,19 @@ __global__ __launch_bounds__(64 * WW) __attribute__((amdgpu_waves_per_eu(8, 8)))
                     for (int m = 0; m < 4; m++) bmk[m] = un_pk(__builtin_elementwise_max(pk_of(bmk[m]), pk_of(P[m])));
                     const int hlast = (int)(P[3] >> 16) - 8 * K;
                     if (l == 63) hand[w][s & 1][r] = hlast;
-                    if (keeps) csave[i0 + r + 1] = hlast;
+                    hl[r] = hlast;
+                }
+            }
+            // the kept boundary column's rows of this chunk in two 16-byte stores (round 6: one 4-byte store per row and kept column was
+            // 101 G of a bench step's 225 G L1 -> L2 write requests, profiles/r06_mem.json)
+            if (keeps) {
+                if (i0 + SWB <= p.n1) {
+                    typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    *(v4i_a4*)(csave + i0 + 1) = (v4i_a4){hl[0], hl[1], hl[2], hl[3]};
+                    *(v4i_a4*)(csave + i0 + 5) = (v4i_a4){hl[4], hl[5], hl[6], hl[7]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < SWB; r++) if (i0 + r < p.n1) csave[i0 + r + 1] = hl[r];
                 }
             }
             const int iend = min(i0 + SWB, p.n1);
