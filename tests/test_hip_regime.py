@@ -179,3 +179,46 @@ def test_sweep_matrices_where_the_band_shifts_every_column(nw, K):
             assert hip.prof_get("sweep")[1] == 2 and hip.prof_get("fill")[1] == 0
     finally:
         hip.set_sweep_min(-1); hip.set_sweep2_min(-1); hip.set_sparse_min(-1); hip.set_sweep_form(0, 0)
+
+
+@pytest.mark.gpu
+def test_align_slabs_are_recycled_without_leaking_state():
+    """AlignData slabs come from a process-wide cache (ps_host.cpp, align_slab_take: no hipMalloc / hipFree per region): a handle that takes
+    over the slab of a destroyed one — same size, smaller, from another thread's stream — computes what a fresh process computes.  Regions of
+    alternating sizes are created, scored and destroyed in turn, on two host threads at once; every result equals the oracle's."""
+    import copy
+    import threading
+    import numpy as np
+    import backends as B
+    from poreseq_amd import synth
+    from poreseq_amd.poreseqcpp import PSAlign
+    from poreseq_amd.util import DEFAULT_PARAMS
+    P = dict(DEFAULT_PARAMS, verbose=0)
+    cases = [(300, 5, 31), (280, 5, 32), (520, 4, 33), (300, 5, 34), (240, 6, 35), (510, 4, 36)]
+    regions = [synth.make_region(L, E, seed, B.oracle_swalign, P) for L, E, seed in cases]
+    want = []
+    for d, ev, _ in regions:
+        pa = B.make_pa(B.OraclePSAlign, d, copy.deepcopy(ev), P)
+        sc = pa.ScoreEvents()
+        n = pa.Refine()
+        want.append((sc, n, pa.sequence))
+    errs = []
+
+    def worker(order):
+        try:
+            for _ in range(3):
+                for k in order:
+                    d, ev, _ = regions[k]
+                    pa = B.make_pa(PSAlign, d, copy.deepcopy(ev), P)
+                    sc = pa.ScoreEvents()          # (every PSAlign call creates and destroys its AlignData: pyx:139-153)
+                    n = pa.Refine()
+                    assert (sc, n, pa.sequence) == want[k], k
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(o,)) for o in ([0, 1, 2, 3, 4, 5], [5, 3, 1, 4, 2, 0])]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
