@@ -23,6 +23,10 @@ Prints ONE JSON line on rank 0 with
                   (queued, read after each host thread's work): algorithmic bytes per launch / average launch duration
                   against the HBM peak; `traffic` from the committed rocprofv3 PMC measurement of the same command
                   (profiles/, tools/pmc_bench.sh), refused when its launch shape disagrees with the live measurement
+  parity_in_run   region 0 of EVERY timed step against the digest the reference's own C++ produced for that region
+                  (tests/golden/bench_regions.json, tests/golden/make_golden_bench.py): true / false / null (another workload)
+  flat keys       "roofline.valu_busy_frac", "roofline.fp64_frac", "roofline.lane_insts_per_band_cell", "roofline.alone_frac",
+                  "cpu_baseline.*", "single_region_10kb_s", ...: scalar duplicates of the nested figures (a record that keeps scalars only)
   north_star_1kb  1 kb / 10x: one region alone, a lock-step batch, and the reference C++ at the same size
   cpu_baseline    the reference's C++ (oracle/_ref; the oracle restatement when that is not built) on the host cores:
                   one thread, one process per core, and a same-size (10 kb) extrapolation from measured unit costs
