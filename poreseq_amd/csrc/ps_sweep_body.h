@@ -502,7 +502,10 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                     asm("v_max_f64 %0, %1, %2" : "=v"(lbest) : "v"(lbest), "v"(nmx));   // (= gt ? nmx : lbest: one v_max instead of two selects; no canonicalisation of the operands)
                     lbr = gt ? r : lbr;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#ifndef PS_SWEEP_ROW_FENCE
+#define PS_SWEEP_ROW_FENCE 1
+#endif
+                if (PS_SWEEP_ROW_FENCE) __builtin_amdgcn_sched_barrier(0);
             }
             bot_m = um; bot_s = us; bot_e = ue;
             if (DIR == 0) lbt = lbest > lbefore ? t : lbt;
