@@ -173,11 +173,11 @@ int ps_make_mutations(ps_align* a, const ps_muts* in, int32_t* nb) {
     return PS_OK;
 }
 int ps_viterbi_mutate(ps_align* a, int32_t nkeep, double skip, double stay, double mmin, double mmax,
-                      int32_t, ps_seqs** out) {
+                      int32_t verbose, ps_seqs** out) {
     if (!a || !out || a->a.E == 0 || nkeep < 0) return fail(PS_ERR_BAD_ARG, "ps_viterbi_mutate");
     NEED_RT();
     std::unique_ptr<ps_seqs> s(new ps_seqs());
-    PS_TRY(viterbi_mutate(rt, &a->a, nkeep, skip, stay, mmin, mmax, &s->v));
+    PS_TRY(viterbi_mutate(rt, &a->a, nkeep, skip, stay, mmin, mmax, &s->v, verbose != 0));
     *out = s.release();
     return PS_OK;
 }

@@ -185,6 +185,14 @@ int find_mutations_multi(Runtime* rt, const std::vector<Align*>& as, const std::
     }
     if (sw_first < pairs.size()) { static const bool trace = getenv("PORESEQ_TRACE") != nullptr; if (trace) fprintf(stderr, "[ps] smith-waterman: %zu pairs, %zu with the realign, the rest in chunks\n", pairs.size(), sw_first); }
     if (pairs.empty()) return PS_OK;
+    // the reference's progress line under `verbose` (cpp/FindMutations.cpp:34-35, 100-109: "Finding mutations", a dot per seed sequence, a
+    // newline); single-handle calls only (a lock-step call has no single line to write)
+    if (R == 1 && as[0]->par.verbose) {
+        fputs("Finding mutations", stderr);
+        for (size_t k = 0; k < seeds[0]->size(); k++) fputc('.', stderr);
+        fputc('\n', stderr);
+        fflush(stderr);
+    }
     par_for((int)als_all.size(), [&](int k) { fillinds(als_all[k]); });
     tk.lap("smith-waterman");
     // (region, seed) pairs whose likelihood vector is not cached yet get (seed x event) alignment jobs
@@ -541,8 +549,18 @@ int viterbi_mutate_multi(Runtime* rt, const std::vector<Align*>& as, const std::
 }
 
 int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, double mmin, double mmax,
-                   std::vector<std::string>* out) {
-    return viterbi_mutate_multi(rt, {a}, {nullptr}, nkeep, skip, stay, mmin, mmax, {out});
+                   std::vector<std::string>* out, bool verbose) {
+    const int rc = viterbi_mutate_multi(rt, {a}, {nullptr}, nkeep, skip, stay, mmin, mmax, {out});
+    if (verbose && rc == PS_OK) {
+        // the reference's progress line (cpp/Viterbi.cpp:258-259, 357-370): "Viterbi", a dot whenever the reference position passes a
+        // multiple of 200, a newline.  The positions walked: from the first event's start to where no event is aligned any more —
+        // counted here from the sequence length (the walk itself runs on the device)
+        fputs("Viterbi", stderr);
+        for (size_t k = 200; k <= a->bases.size(); k += 200) fputc('.', stderr);
+        fputc('\n', stderr);
+        fflush(stderr);
+    }
+    return rc;
 }
 
 }  // namespace ps

@@ -1371,6 +1371,14 @@ static int score_mutations_planned(Runtime* rt, const std::vector<Align*>& as, c
                                    const std::vector<std::vector<Mut>*>& outs, const std::vector<double*>* delta_out, std::vector<EditPlan>& plan) {
     Tick tk("score_mutations");
     const int R = (int)as.size();
+    // the reference's progress line under `verbose` (cpp/MakeMutations.cpp:28-32, 55-66: "Scoring (<width>)", a dot per event, a newline);
+    // a lock-step call over several AlignData has no single line to write: only the single-handle call speaks
+    if (R == 1 && as[0]->par.verbose) {
+        fprintf(stderr, "Scoring (%d)", (int)as[0]->par.scoring_width);
+        for (int e = 0; e < as[0]->E; e++) fputc('.', stderr);
+        fputc('\n', stderr);
+        fflush(stderr);
+    }
     {   // experiment: how much of a bench step is the latency of a chain?  PORESEQ_DEBUG_SLEEP_US of host sleep per ScoreMutations call
         static const int us = getenv("PORESEQ_DEBUG_SLEEP_US") ? atoi(getenv("PORESEQ_DEBUG_SLEEP_US")) : 0;
         if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us));
@@ -1595,6 +1603,7 @@ void find_point_mutations(const Align* a, std::vector<Mut>* out) {
         m.orig.clear();
         for (int k = 0; k < 4; k++) { m.mut.assign(1, B4[k]); out->push_back(m); }
     }
+    if (a->par.verbose) { fputs("Point ", stderr); fflush(stderr); }   // cpp/FindMutations.cpp:230-231
 }
 
 static bool by_score_desc(const Mut& x, const Mut& y) { return x.score > y.score; }  // cpp/MakeMutations.cpp:16-17
@@ -1603,7 +1612,7 @@ static bool by_score_desc(const Mut& x, const Mut& y) { return x.score > y.score
 // libstdc++ gives the reference's (unstable) order for tied scores.
 // One greedy pass (host only): sorts, applies the positive edits, returns the mutated-base count and the edits that
 // were disabled on the way (the reference re-scores and recurses on those when there are more than ten).
-static int greedy_apply(Align* a, std::vector<Mut>& muts, std::vector<Mut>* later) {
+static int greedy_apply(Align* a, std::vector<Mut>& muts, std::vector<Mut>* later, bool talk) {
     const int spacing = 10;
     int nb = 0;
     later->clear();
@@ -1631,6 +1640,7 @@ static int greedy_apply(Align* a, std::vector<Mut>& muts, std::vector<Mut>* late
         muts.swap(kept);
     }
     if (muts.empty()) return 0;
+    if (talk) { fprintf(stderr, "Testing %zu mutations...\n", muts.size()); fflush(stderr); }   // cpp/MakeMutations.cpp:91-95
     bool changed = false;
     // cpp/MakeMutations.cpp:95-139 with the edits' numbers in flat arrays: the inner loop over all later edits (defer the ones
     // within `spacing` of the applied edit, shift the ones behind it) is then a branch-free integer loop the compiler vectorises —
@@ -1646,6 +1656,10 @@ static int greedy_apply(Align* a, std::vector<Mut>& muts, std::vector<Mut>* late
         if (dfr[i] || muts[i].score < 0) { if (dfr[i]) muts[i].score = -1; later->push_back(muts[i]); continue; }
         a->bases = apply_edit(a->bases, muts[i]);
         changed = true;
+        if (talk && a->par.verbose > 1) {   // cpp/MakeMutations.cpp:112-118 (operator<< of a double: six significant digits)
+            fprintf(stderr, "Kept mutation %zu at %d of %zu to %zu with score %g\n", i, st[i], muts[i].orig.size(), muts[i].mut.size(), muts[i].score);
+            fflush(stderr);
+        }
         nb += (int)std::max(muts[i].orig.size(), muts[i].mut.size());
         const int si = st[i], ei = si + ml[i], oi = si + ol[i], d = ml[i] - ol[i];
         int* __restrict__ pst = st.data();
@@ -1677,7 +1691,7 @@ int make_mutations_multi(Runtime* rt, const std::vector<Align*>& as, std::vector
     while (!active.empty()) {
         par_for((int)active.size(), [&](int q) {
             const int k = active[q];
-            (*nbases)[k] += greedy_apply(as[k], muts[k], &later[k]);
+            (*nbases)[k] += greedy_apply(as[k], muts[k], &later[k], R == 1 && as[k]->par.verbose);
         });
         tk.lap("greedy apply");
         std::vector<int> next;

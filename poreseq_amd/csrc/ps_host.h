@@ -148,7 +148,7 @@ void find_point_mutations(const Align* a, std::vector<Mut>* out);
 int make_mutations(Runtime* rt, Align* a, std::vector<Mut> muts, int* nbases);
 int find_mutations(Runtime* rt, Align* a, const std::vector<std::string>& seeds, std::vector<Mut>* out);
 int viterbi_mutate(Runtime* rt, Align* a, int nkeep, double skip, double stay, double mmin, double mmax,
-                   std::vector<std::string>* out);
+                   std::vector<std::string>* out, bool verbose = false);
 int debug_fill(Runtime* rt, Align* a, int ev, int dir, double* main, double* stay, uint8_t* sm, uint8_t* ss);
 
 }  // namespace ps

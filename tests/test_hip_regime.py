@@ -222,3 +222,40 @@ def test_align_slabs_are_recycled_without_leaking_state():
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.gpu
+def test_verbose_diagnostics_read_like_the_reference():
+    """`verbose` (cpp/MakeMutations.cpp:28-32, 55-66, 91-95, 112-118; cpp/FindMutations.cpp:34-35, 100-109, 230-231; cpp/Viterbi.cpp:258-259):
+    a single PSAlign's Refine / Mutate calls write the reference's progress lines to stderr.  Refine's text — "Point ", "Scoring (w)" with a
+    dot per event, "Testing N mutations...", "Kept mutation i at s of a to b with score x" — equals the reference C++'s character for
+    character where that library is built (oracle/_ref)."""
+    import subprocess, sys
+    import backends as B
+    code = (
+        "import sys, copy; sys.path[:0] = [%r, %r]\n"
+        "import backends as B\n"
+        "from poreseq_amd import synth\n"
+        "from poreseq_amd.poreseqcpp import PSAlign\n"
+        "from poreseq_amd.util import DEFAULT_PARAMS\n"
+        "P = dict(DEFAULT_PARAMS, verbose=2)\n"
+        "draft, events, truth = synth.make_region(300, 5, 41, B.oracle_swalign, dict(P, verbose=0))\n"
+        "cls = {'hip': PSAlign, 'ref': B.RefPSAlign}[sys.argv[1]]\n"
+        "pa = B.make_pa(cls, draft, copy.deepcopy(events), P)\n"
+        "B.reset_rand()\n"
+        "sys.stderr.write('== Refine\\n'); sys.stderr.flush(); n = pa.Refine()\n"
+        "sys.stderr.write('\\n== Mutate\\n'); sys.stderr.flush(); pa.Mutate(seqs='viterbi')\n"
+        "print(n, pa.sequence)\n"
+    ) % (B.ROOT, __import__("os").path.join(B.ROOT, "tests"))
+    def run(which):
+        r = subprocess.run([sys.executable, "-c", code, which], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout, r.stderr
+    out, err = run("hip")
+    refine, mutate = err.split("== Mutate")[0], err.split("== Mutate")[1]
+    assert "Point Scoring (20)....." in refine and "Testing " in refine and " mutations..." in refine and "Kept mutation 0 at " in refine
+    assert "Viterbi" in mutate and "Finding mutations" in mutate and "Scoring (" in mutate
+    if B.have_ref():
+        rout, rerr = run("ref")
+        assert rout == out
+        assert rerr.split("== Mutate")[0] == refine          # Refine's diagnostics: character for character
