@@ -676,8 +676,11 @@ std::mutex g_aslab_mu;
 std::vector<CachedSlab> g_aslabs;
 size_t g_aslab_bytes = 0;
 size_t aslab_cache_limit() {
-    static const size_t lim = getenv("PORESEQ_ALIGN_CACHE_GB") ? (size_t)(atof(getenv("PORESEQ_ALIGN_CACHE_GB")) * 1e9) : (size_t)8e9;
-    return lim;
+    // 8 GB, at most 3 % of this process's part of the device (ranks that share a GPU: ps_set_device_fraction)
+    static const double env = getenv("PORESEQ_ALIGN_CACHE_GB") ? atof(getenv("PORESEQ_ALIGN_CACHE_GB")) * 1e9 : -1.0;
+    if (env >= 0) return (size_t)env;
+    const size_t plan = device_plan_bytes();
+    return plan ? std::min<size_t>((size_t)8e9, (size_t)(0.03 * (double)plan)) : (size_t)8e9;
 }
 }  // namespace
 
