@@ -312,7 +312,12 @@ __device__ __forceinline__ void sweep_body(const BatchD& b, const SweepD& sw, co
                 v.x = cw[r0 / 4]; v.y = cw[r0 / 4 + 1];
                 *(PS_GLOBAL v2i*)p = v;
             } else if (sz == 4) {
-                *(PS_GLOBAL unsigned*)p = cw[r0 / 4];
+#ifndef PS_CODES_NT
+#define PS_CODES_NT 0
+#endif
+                // (PS_CODES_NT: the codes as non-temporal stores — 7 MB per sweep that only the backtrace reads, sparsely, a kernel later)
+                if (PS_CODES_NT) __builtin_nontemporal_store(cw[r0 / 4], (PS_GLOBAL unsigned*)p);
+                else *(PS_GLOBAL unsigned*)p = cw[r0 / 4];
             } else {
                 // a register with nrow < 4 rows holds its first row in field nrow - 1: the plane's rows r0 .. r0 + sz - 1 are the sz
                 // fields from field nrow - (r0 mod 4) - sz on, last row lowest
