@@ -149,6 +149,7 @@ constexpr int BTM = 8;   // the tile prefetched during a walk overlaps the curre
 struct SkewCodes {       // FLG[s][slot], s = i + j, slot = i mod P
     const unsigned short* flg; int P; int sti;
     static constexpr bool ROWFAST = false;
+    static constexpr bool TWO_PASS = false;   // (words are stored as the walker reads them: nothing to decode)
     __device__ __forceinline__ void prep(int ti, int, int) { sti = __builtin_amdgcn_readfirstlane(ti > 0 ? ti % P : 0); }
     // fetch: the load of one cell's word; decode: what the walker reads (here: the word itself)
     __device__ __forceinline__ unsigned fetch(int ti, int tj, int a, int c) const {
@@ -167,6 +168,22 @@ template <int NT, class SRC>
 __device__ __forceinline__ void bt_load(unsigned short (*__restrict__ dst)[BT + 2], SRC& src, const int ti, const int tj, const int t) {
     constexpr int NQ = (BT * BT + NT - 1) / NT;
     src.prep(ti, tj, t);
+    if constexpr (!SRC::TWO_PASS) {
+        // (a source whose words need no decoding: all loads of a thread in flight before the first LDS store, as since round 2)
+        unsigned short tmp[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int idx = min(t + NT * q, BT * BT - 1);
+            const int a = SRC::ROWFAST ? idx % BT : idx / BT, c = SRC::ROWFAST ? idx / BT : idx % BT;
+            tmp[q] = src.decode(src.fetch(ti, tj, a, c), ti, tj, a, c);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int idx = t + NT * q;
+            if (idx < BT * BT) { const int a = SRC::ROWFAST ? idx % BT : idx / BT, c = SRC::ROWFAST ? idx / BT : idx % BT; dst[a][c] = tmp[q]; }
+        }
+        return;
+    }
     unsigned raw[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -189,6 +206,9 @@ __device__ __forceinline__ void bt_walk(const JobD& J, SRC& src) {
     const JobOut O = *J.out;
     if (O.inert) return;  // stripe_width == 0: the event is left untouched
     const int tid = threadIdx.x, n0 = J.n0;
+    // (wave priority for the WALKER wave only: with the tile loaders raised too, the kernel alone was 14 % slower than without any
+    //  priority — 1.24 against 1.08 ms per 10 kb job — the loaders' decode work then competes with the walk it feeds)
+    if (PS_WALKER_PRIO > 0 && tid < 64) __builtin_amdgcn_s_setprio(PS_WALKER_PRIO);
     double* __restrict__ ra = J.ra;
     long long* __restrict__ rlw = (long long*)J.rl;
     for (int t = tid; t < n0; t += 256) { ra[t] = 0.0; rlw[t] = 0ll; }

@@ -784,7 +784,6 @@ __global__ __launch_bounds__(64) void k_prefix(BatchD b, int ndir) {
 
 // (the backtrace walker is a template shared with ps_sweep.hip: ps_dev.h, bt_walk)
 __global__ __launch_bounds__(256) void k_backtrace(BatchD b) {
-    chain_priority();
     const JobD& J = b.jobs[blockIdx.x];
     SkewCodes src;
     src.flg = b.flg + J.mat_off[0]; src.P = J.P; src.sti = 0;

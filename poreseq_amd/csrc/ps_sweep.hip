@@ -156,6 +156,7 @@ struct StripCodes {
     int nl;                                 // lanes of a sweep (64 per wave): strip q sits on lane q mod nl
     int ci0, ci1, cp0, cp1, cst;            // lane l: band of column tj - l, band of the column before it, its 5-mer (prep)
     static constexpr bool ROWFAST = true;   // consecutive threads take consecutive rows: K contiguous bytes per strip
+    static constexpr bool TWO_PASS = true;  // bt_load: every code word and the column tables in flight before the first decode
     // What the sweep's predicate bits leave to the reader — does the cell exist (its column has a 5-mer, the row is in the column's
     // band), is a MATCH real or implicit (cpp/Alignment.cpp:207-220: p0 < i <= p1 of the previous column's band) — hangs on the
     // COLUMN: lane l of every loading wave fetches the three table entries of column tj - l once per tile, together with the tile's
@@ -192,7 +193,6 @@ struct StripCodes {
 
 template <int K>
 __global__ __launch_bounds__(256) void k_backtrace_s(BatchD b, SweepD sw) {
-    chain_priority();
     const JobD& J = b.jobs[blockIdx.x];
     const SweepJob& SJ = sw.sj[blockIdx.x * sw.ndir];
     StripCodes<K> src;
