@@ -22,6 +22,38 @@ def reverse_complement(seq):
     return "".join(_COMP.get(c, c) for c in reversed(seq))
 
 
+def _text(x):
+    return x.decode() if isinstance(x, bytes) else str(x)
+
+
+def _kmer_offsets(sequence, kmers):
+    """Offset of every k-mer of a 2D alignment table in the 2D sequence: each k-mer is searched from where the one before it was found
+    (str.find; a k-mer that does not occur gives -1, and the search for the next one then starts at -1 — Python's own meaning of a
+    negative start, one character from the end — as the reference's walk does, EventData.py:131-138)."""
+    out = np.zeros(len(kmers), dtype=np.int64)
+    at = 0
+    for n, k in enumerate(kmers):
+        at = sequence.find(_text(k), at)
+        out[n] = at
+    return out
+
+
+def _reverse_complement_states():
+    """perm[x] = the 5-mer state of x's reverse complement.  A state is five 2-bit digits, first base most significant, A C G T = 0 1 2 3:
+    complementing a base is 3 - digit, reversing the 5-mer reverses the digits."""
+    x = np.arange(1024)
+    digits = [(x >> (2 * k)) & 3 for k in range(5)]           # digits[0]: the LAST base
+    perm = np.zeros(1024, dtype=np.int64)
+    for k, d in enumerate(digits):
+        perm |= (3 - d) << (2 * (4 - k))                       # the last base's complement becomes the first base
+    return perm
+
+
+_RC_STATES = _reverse_complement_states()
+_PER_LEVEL = ("mean", "stdv", "length", "start", "ref_align", "ref_like")     # arrays with one entry per level
+_PER_STATE = ("level_mean", "level_stdv", "sd_mean", "sd_stdv")               # model tables with one entry per 5-mer
+
+
 class PSModel:
     """poreseq/EventData.py:46-78 (same attribute names and fall-back probabilities)."""
 
@@ -64,33 +96,28 @@ class PSEvent:
         A complement strand is flipped (levels reversed, model states mapped to their reverse complements) and keeps its sequence,
         so that template and complement point the same way (EventData.py:173-175)."""
         sequence = str(sequence)
-        alinds = np.asarray(alignment)
-        # where each k-mer of the 2D alignment sits in the 2D sequence: a forward walk with str.find (EventData.py:131-138)
-        seqinds = 0 * alinds
-        curind = 0
-        for i in range(len(alinds)):
-            k = kmers[i]
-            curind = sequence.find(k.decode() if isinstance(k, bytes) else str(k), curind)
-            seqinds[i] = curind
-        mean = np.asarray(events["mean"], dtype=np.float64)
-        start = np.asarray(events["start"], dtype=np.float64)
-        ev = cls(mean - attrs["drift"] * (start - start[0]), events["stdv"], sequence=sequence)
-        ev.length = np.array(events["length"], dtype=np.float64)
-        ev.start = np.array(start, dtype=np.float64)
-        # seed ref_align with the self-alignment: every aligned k-mer's level points at the k-mer's position (EventData.py:159-163)
-        lvl = alinds > 0
-        ev.ref_align[alinds[lvl]] = seqinds[lvl]
+        level_of_row = np.asarray(alignment)                     # per row of the 2D alignment table: this strand's level (<= 0: none)
+        offset_of_row = _kmer_offsets(sequence, kmers).astype(level_of_row.dtype)
+        field = lambda table, name: np.asarray(table[name], dtype=np.float64)
+        start = field(events, "start")
+        ev = cls(field(events, "mean") - attrs["drift"] * (start - start[0]), events["stdv"], sequence=sequence)   # drift off the levels
+        ev.length = field(events, "length").copy()
+        ev.start = start.copy()
+        # the self-alignment seeds ref_align: the level of every aligned row points at its k-mer's offset in the 2D sequence
+        # (EventData.py:159-163; rows that share a level: the last one wins, as in a fancy-indexed assignment)
+        aligned = level_of_row > 0
+        ev.ref_align[level_of_row[aligned]] = offset_of_row[aligned]
+        # the strand's pore model, scaled to this read (EventData.py:141-157)
         m = PSModel()
-        m.level_mean = np.asarray(model["level_mean"], dtype=np.float64) * attrs["scale"] + attrs["shift"]
-        m.level_stdv = np.asarray(model["level_stdv"], dtype=np.float64) * attrs["var"]
-        m.sd_mean = np.asarray(model["sd_mean"], dtype=np.float64) * attrs["scale_sd"]
-        m.sd_stdv = np.asarray(model["sd_stdv"], dtype=np.float64) / np.sqrt(attrs["var_sd"])
-        name = attrs.get("model_file", "") if hasattr(attrs, "get") else attrs["model_file"]
-        m.name = name.decode() if isinstance(name, bytes) else str(name)
+        m.level_mean = field(model, "level_mean") * attrs["scale"] + attrs["shift"]
+        m.level_stdv = field(model, "level_stdv") * attrs["var"]
+        m.sd_mean = field(model, "sd_mean") * attrs["scale_sd"]
+        m.sd_stdv = field(model, "sd_stdv") / np.sqrt(attrs["var_sd"])
+        m.name = _text(attrs.get("model_file", "") if hasattr(attrs, "get") else attrs["model_file"])
         m.complement = bool(complement)
         ev.model = m
         if m.complement:
-            ev.flip(False)
+            ev.flip(False)                                       # complement strands are stored the other way round; the sequence stays
         return ev
 
     @classmethod
@@ -123,21 +150,18 @@ class PSEvent:
         return _copy.deepcopy(self)
 
     def flip(self, flip_sequence=True):
-        """Reverse the event in place and map every model state to its reverse complement (EventData.py:182-224): state x's
-        complement is 1023 - x (two bits per base, A/T and C/G are bitwise complements), its reverse swaps the five 2-bit digits.
-        With flip_sequence the sequence is reverse-complemented too and every aligned ref_align index i becomes len - i."""
-        for k in ("mean", "stdv", "length", "start", "ref_align", "ref_like"):
-            if hasattr(self, k):
-                setattr(self, k, getattr(self, k)[::-1])
-        flips = 1023 - np.arange(1024)
-        flips = (((flips & 0b11) << 8) | ((flips >> 8) & 0b11) | ((flips & 0b1100) << 4) | ((flips >> 4) & 0b1100) | (flips & 0b110000))
-        for k in ("level_mean", "level_stdv", "sd_mean", "sd_stdv"):
-            setattr(self.model, k, np.asarray(getattr(self.model, k))[flips])
+        """Turn the event round in place (EventData.py:182-224): the per-level arrays run backwards and every model table is read
+        through the reverse-complement permutation of the 5-mer states (`_RC_STATES`).  With flip_sequence the sequence is
+        reverse-complemented too and an aligned level's ref_align i becomes len(sequence) - i (0 stays "not aligned")."""
+        for name in _PER_LEVEL:
+            if hasattr(self, name):
+                setattr(self, name, getattr(self, name)[::-1])
+        for name in _PER_STATE:
+            setattr(self.model, name, np.asarray(getattr(self.model, name))[_RC_STATES])
         if flip_sequence:
             self.sequence = reverse_complement(self.sequence)
-            self.ref_align = np.array(self.ref_align, dtype=np.float64)
-            ra0 = self.ref_align > 0
-            self.ref_align[ra0] = len(self.sequence) - self.ref_align[ra0]
+            ra = np.array(self.ref_align, dtype=np.float64)
+            self.ref_align = np.where(ra > 0, len(self.sequence) - ra, ra)
         self.makecontiguous()
         self.flipped = not self.flipped
 
@@ -148,15 +172,20 @@ class PSEvent:
                     setattr(obj, k, np.ascontiguousarray(v, dtype=np.float64))
 
     def mapaligns(self, pairs):
-        """Re-map ref_align through aligned index pairs (EventData.py:226-256): unique in x,
-        linear interpolation, round, 0 outside the paired range."""
+        """Carry ref_align over to another sequence through aligned (index here, index there) pairs (EventData.py:226-256): of
+        pairs that share their first index the first one counts; an aligned level's index is interpolated linearly between the
+        pairs and rounded (numpy: half to even); levels that are not aligned, or whose index lies outside the paired range, get 0."""
         pairs = np.asarray(pairs)
-        refal = self.ref_align
-        keep = refal > 0
-        self.ref_align = 0 * self.ref_align
-        _, uinds = np.unique(pairs[:, 0], return_index=True)
-        pairs = pairs[uinds, :]
-        self.ref_align[keep] = np.round(np.interp(refal[keep], pairs[:, 0], pairs[:, 1], 0, 0))
+        src = pairs[:, 0]
+        order = np.argsort(src, kind="stable")
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = src[order][1:] != src[order][:-1]
+        xs, ys = src[order][first], pairs[order, 1][first]       # strictly increasing sources, each with its first partner
+        old = self.ref_align
+        new = np.zeros_like(old)
+        on = old > 0
+        new[on] = np.round(np.interp(old[on], xs, ys, left=0, right=0))
+        self.ref_align = new
         self.makecontiguous()
 
     def setparams(self, params):
