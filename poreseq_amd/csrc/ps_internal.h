@@ -199,7 +199,7 @@ struct SweepD {
     int2* band;
     int* qlo;
     int* qhi;               // lowest / highest strip in band per step (-1: none)
-    unsigned char* codes;   // one byte of storage per cell, seven raw predicate bits of the fill (ps_sweep_body.h: CB_*, code_fetch)
+    unsigned char* codes;   // one byte of storage per cell, seven raw predicate bits of the fill (ps_codes.h: CB_*, code_fetch)
     StripBest* sb;
     int* maxwin;            // widest window of strips in band on one step, over the batch
     int K;

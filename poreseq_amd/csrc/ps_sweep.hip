@@ -171,7 +171,7 @@ struct StripCodes {
         }
     }
     // fetch: the cell's 32 / 16 / 8-bit code word (its address must not wait for the column tables: any row >= 1 of any column >= 1
-    // has one, in band or not); decode: the walker's step word from the sweep's raw predicate bits (ps_sweep_body.h, CB_*)
+    // has one, in band or not); decode: the walker's step word from the sweep's raw predicate bits (ps_codes.h, CB_*)
     __device__ __forceinline__ unsigned fetch(int ti, int tj, int a, int c) const {
         const int rs = max(ti - a, 1), col = max(tj - c, 1);
         const int q = (rs - 1) / K, rr = (rs - 1) - q * K;
